@@ -1,0 +1,500 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by importing the Python reference.
+
+Runs ONLY in the build container (needs /root/reference, CPU only).  The reference is
+imported from a symlink under /tmp with the absent third-party modules stubbed
+(SURVEY.md section 8c); nothing of it is copied here -- the outputs are DATA (inputs +
+expected outputs of the reference's own functions), a few hundred KB in total.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Fixture groups (names follow SURVEY.md 8c):
+  g01_masks      generate_mask bool arrays                       (int, bit exact)
+  g02_sens       SENSE coil maps f64 + anchors
+  g03_fft        i2k_complex / k2i_complex
+  g04_sense      SENSE forward / adjoint / SSOS (T=1 mask variant and live T=24 variant)
+  g05_prox       L2Penalty / SingleCoil outputs
+  g06_sigmas     get_sigmas for the shipped schedules
+  g07_layers     InstanceNorm2dPlus / ConvMeanPool / ResidualBlock / RefineBlock / tiny
+                 NCSNv2Deepest known-answer tests with the weights stored alongside
+  g08_ald        ALDInvSegProximalRealImag + ALDUnconditionalSampler trajectories with
+                 the injected noise recorded
+  g09_upfirdn    upfirdn2d_native / upsample_2d / downsample_2d
+  g10_biasact    CPU fused_leaky_relu
+  g11_temporal   reshape_temporal_dim, FiniteDiff
+  g15_fullnet    full-size NCSNv2Deepest (ngf=128, 128x128) forward on synthetic weights
+                 produced by inverseproblemwithdiffusionmodel_amd.synthetic.synth_state_dict (weights NOT stored)
+"""
+import hashlib
+import io
+import os
+import sys
+import contextlib
+from argparse import Namespace
+from unittest.mock import MagicMock
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+ALIAS_ROOT = "/tmp/ipdm_oracle"
+
+
+def _import_reference():
+    os.makedirs(ALIAS_ROOT, exist_ok=True)
+    link = os.path.join(ALIAS_ROOT, "InverseProblemWithDiffusionModel")
+    if not os.path.islink(link):
+        os.symlink(REF, link)
+    sys.path.insert(0, ALIAS_ROOT)
+    sys.path.insert(0, REPO)
+    absent = ["monai", "monai.networks", "monai.networks.nets", "monai.transforms", "monai.data",
+              "monai.losses", "monai.utils", "monai.metrics", "monai.inferers", "pytorch_lightning",
+              "pytorch_lightning.callbacks", "pytorch_lightning.loggers", "skimage", "skimage.metrics",
+              "torchvision", "torchvision.transforms", "torchvision.datasets", "torchvision.utils",
+              "SimpleITK", "torchmetrics", "tensorboard", "torch.utils.tensorboard", "kornia", "cv2",
+              "nibabel", "sigpy", "ml_collections"]
+    for m in absent:
+        if m not in sys.modules:
+            sys.modules[m] = MagicMock()
+    import torch.utils.cpp_extension as cpp_ext
+    cpp_ext.load = lambda *a, **k: MagicMock()   # never JIT the reference's CUDA sources
+
+
+_import_reference()
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+from InverseProblemWithDiffusionModel.ncsn import linear_transforms as ref_lt  # noqa: E402
+from InverseProblemWithDiffusionModel.ncsn.linear_transforms import undersampling_fourier as ref_uf  # noqa: E402
+from InverseProblemWithDiffusionModel.ncsn.linear_transforms.finite_diff import FiniteDiff as RefFiniteDiff  # noqa: E402
+from InverseProblemWithDiffusionModel.ncsn.models import proximal_op as ref_prox  # noqa: E402
+from InverseProblemWithDiffusionModel.ncsn.models import ALD_optimizers as ref_ald  # noqa: E402
+from InverseProblemWithDiffusionModel.ncsn.models import get_sigmas as ref_get_sigmas  # noqa: E402
+from InverseProblemWithDiffusionModel.ncsn.models import ncsnv2 as ref_ncsnv2  # noqa: E402
+from InverseProblemWithDiffusionModel.ncsn.models import layers as ref_layers  # noqa: E402
+from InverseProblemWithDiffusionModel.ncsn.models import normalization as ref_norm  # noqa: E402
+from InverseProblemWithDiffusionModel.helpers import utils as ref_utils  # noqa: E402
+import importlib  # noqa: E402
+ref_upfirdn = importlib.import_module("InverseProblemWithDiffusionModel.op.upfirdn2d")   # op/__init__ shadows the names
+ref_fused = importlib.import_module("InverseProblemWithDiffusionModel.op.fused_act")
+from InverseProblemWithDiffusionModel.models import up_or_down_sampling as ref_updown  # noqa: E402
+
+quiet = contextlib.redirect_stdout(io.StringIO())
+
+# mask parameter sets; the first three are the reference's (undersampling_fourier.py:68-73),
+# R40 is the build's choice (no R=40 set exists in the reference)
+MASK_PARAMS = {
+    "R20": dict(sw=0.07, sm=0.3, sa=0.01782),
+    "R16": dict(sw=0.07926, sm=0.42, sa=0.02),
+    "R8": dict(sw=0.196, sm=0.5, sa=0.02),
+    "R40": dict(sw=0.07, sm=0.11, sa=0.0065),
+}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB  ({len(arrays)} arrays)")
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def tiny_config(ngf=4, num_classes=10, sigma_begin=1.0, sigma_end=0.01, channels=1, image_size=32):
+    return Namespace(
+        device=torch.device("cpu"),
+        data=Namespace(channels=channels, image_size=image_size, logit_transform=False, rescaled=False,
+                       uniform_dequantization=False, gaussian_dequantization=False),
+        model=Namespace(ngf=ngf, num_classes=num_classes, sigma_begin=sigma_begin, sigma_end=sigma_end,
+                        sigma_dist="geometric", normalization="InstanceNorm++", nonlinearity="elu",
+                        spec_norm=False),
+        recons=Namespace(sigma_dist="geometric", sigma_begin=sigma_begin, sigma_end=sigma_end,
+                         num_classes=num_classes),
+        sampling=Namespace(n_steps_each=3, step_lr=9e-7, final_only=True, denoise=True),
+    )
+
+
+def t1_mask_patch(params):
+    """RandomUndersamplingFourier._generate_mask restricted to the T=1 variant the reference keeps
+    commented out (undersampling_fourier.py:72-73): generate_mask(1, W, ...).unsqueeze(1)."""
+    def _gen(self):
+        torch.random.manual_seed(self.seed)
+        C, H, W = self.in_shape
+        return ref_lt.generate_mask(1, W, seed=self.seed, **params).unsqueeze(1)
+    return _gen
+
+
+# ---------------------------------------------------------------------------------------------
+def g01_masks():
+    out = {}
+    for seed in range(4):
+        out[f"R20_T1_N128_seed{seed}"] = npy(ref_lt.generate_mask(1, 128, seed=seed, **MASK_PARAMS["R20"]))
+        out[f"R40_T1_N128_seed{seed}"] = npy(ref_lt.generate_mask(1, 128, seed=seed, **MASK_PARAMS["R40"]))
+    out["R16_T24_N128_seed0"] = npy(ref_lt.generate_mask(24, 128, seed=0, **MASK_PARAMS["R16"]))
+    out["R8_T24_N128_seed0"] = npy(ref_lt.generate_mask(24, 128, seed=0, **MASK_PARAMS["R8"]))
+    out["R8_T1_N64_seed5"] = npy(ref_lt.generate_mask(1, 64, seed=5, **MASK_PARAMS["R8"]))
+    out["default_T3_N32_seed1"] = npy(ref_lt.generate_mask(3, 32, seed=1))
+    out["R20_T1_N256_seed0"] = npy(ref_lt.generate_mask(1, 256, seed=0, **MASK_PARAMS["R20"]))
+    for k, v in out.items():
+        assert v.dtype == np.bool_, (k, v.dtype)
+    print("  R40 seed0 lines:", int(out["R40_T1_N128_seed0"].sum()),
+          " R20 seed0 lines:", int(out["R20_T1_N128_seed0"].sum()))
+    save("g01_masks", **out)
+
+
+def g02_sens():
+    out = {}
+    with quiet:
+        for (H, W) in [(32, 32), (128, 128), (24, 64)]:
+            op = ref_uf.SENSE("exp", 4, 20, 0.04, (1, H, W), seed=0)
+            maps = npy(op.sens_maps)
+            assert maps.dtype == np.float64
+            anchors = []
+            for i in range(4):
+                np.random.seed(0 + i)
+                anchors.append((np.random.choice(H), np.random.choice(W)))
+            key = f"{H}x{W}"
+            out[f"anchors_{key}"] = np.array(anchors, dtype=np.int64)
+            if H * W <= 2048:
+                out[f"maps_{key}"] = maps
+            else:
+                out[f"maps_{key}_rows8"] = maps[:, ::8, :]
+                out[f"maps_{key}_sha256"] = np.frombuffer(
+                    hashlib.sha256(np.ascontiguousarray(maps).tobytes()).digest(), dtype=np.uint8)
+        op = ref_uf.SENSE("exp", 3, 20, 0.04, (1, 32, 32), seed=7)
+        out["maps_32x32_seed7_n3"] = npy(op.sens_maps)
+    save("g02_sens", **out)
+
+
+def g03_fft():
+    out = {}
+    g = torch.Generator().manual_seed(3)
+    for shape in [(2, 1, 8, 8), (1, 2, 7, 9), (1, 1, 32, 32), (1, 1, 6, 5)]:
+        x = torch.complex(torch.randn(shape, generator=g), torch.randn(shape, generator=g))
+        key = "x".join(map(str, shape))
+        out[f"x_{key}"] = npy(x)
+        out[f"i2k_{key}"] = npy(ref_lt.i2k_complex(x))
+        out[f"k2i_{key}"] = npy(ref_lt.k2i_complex(x))
+    save("g03_fft", **out)
+
+
+def g04_g05_sense_prox():
+    out4, out5 = {}, {}
+    g = torch.Generator().manual_seed(4)
+    H = W = 32
+    orig = ref_uf.RandomUndersamplingFourier._generate_mask
+    try:
+        ref_uf.RandomUndersamplingFourier._generate_mask = t1_mask_patch(MASK_PARAMS["R8"])
+        with quiet:
+            op = ref_uf.SENSE("exp", 4, 8, 0.04, (1, H, W), seed=0)
+        x = torch.complex(torch.randn(2, 1, H, W, generator=g), torch.randn(2, 1, H, W, generator=g))
+        y = op(x)
+        s = torch.complex(torch.randn(4, 2, 1, H, W, generator=g), torch.randn(4, 2, 1, H, W, generator=g))
+        out4["mask_T1"] = npy(op.random_under_fourier.mask)
+        out4["x"] = npy(x)
+        out4["Ax"] = npy(y)
+        out4["s"] = npy(s)
+        out4["AHs"] = npy(op.conj_op(s))
+        out4["ssos_s"] = npy(op.SSOS(s))
+        out4["loglh_grad"] = npy(op.log_lh_grad(x, s, 0.7))
+        # L2Penalty on the SENSE operator
+        z = torch.complex(torch.randn(2, 1, H, W, generator=g), torch.randn(2, 1, H, W, generator=g))
+        out5["z"] = npy(z)
+        out5["y"] = npy(y)
+        prox = ref_prox.L2Penalty(op)
+        for i, (alpha, lamda) in enumerate([(0.9, 1.0), (3.0, 0.5), (9e-7, 1.0)]):
+            with quiet:
+                xs = prox(z, y, alpha, lamda)
+            torch.set_grad_enabled(True)
+            out5[f"l2_sense_{i}_alpha_lamda"] = np.array([alpha, lamda], dtype=np.float64)
+            out5[f"l2_sense_{i}_x"] = npy(xs)
+        # single-coil operator: L2Penalty (K = B) and SingleCoil closed form
+        with quiet:
+            sc = ref_uf.RandomUndersamplingFourier(8, 0.04, (1, H, W), seed=2)
+        ysc = sc(x)
+        out5["sc_mask"] = npy(sc.mask)
+        out5["sc_y"] = npy(ysc)
+        out5["sc_Ax_adj"] = npy(sc.conj_op(ysc))
+        with quiet:
+            out5["l2_sc_x"] = npy(ref_prox.L2Penalty(sc)(z, ysc, 0.9, 1.0))
+            torch.set_grad_enabled(True)
+            p = ref_prox.SingleCoil(sc)
+            xs = p(z, ysc, 0.8, 2.0)
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out5["singlecoil_check"] = np.array(float(p.check_solution(xs, z, ysc, 0.8, 2.0)))
+        out5["singlecoil_x"] = npy(xs)
+        out5["singlecoil_alpha_lamda"] = np.array([0.8, 2.0])
+    finally:
+        ref_uf.RandomUndersamplingFourier._generate_mask = orig
+    # live (hard-wired T=24, "R=16") variant: a (24,1,H,W) stack broadcasts against (24,1,1,W)
+    with quiet:
+        op24 = ref_uf.SENSE("exp", 4, 16, 0.04, (1, H, W), seed=0)
+    x24 = torch.complex(torch.randn(24, 1, H, W, generator=g), torch.randn(24, 1, H, W, generator=g))
+    out4["mask_T24"] = npy(op24.random_under_fourier.mask)
+    out4["x24"] = npy(x24)
+    out4["Ax24"] = npy(op24(x24))
+    save("g04_sense", **out4)
+    save("g05_prox", **out5)
+
+
+def g06_sigmas():
+    out = {}
+    for name, (s0, s1, L) in {"acdc": (348, 0.01, 2311), "cine127": (60, 0.01, 1000),
+                              "cine127_1d": (40, 0.01, 400), "mnist": (50, 0.01, 232)}.items():
+        cfg = tiny_config(num_classes=L, sigma_begin=s0, sigma_end=s1)
+        sig = npy(ref_get_sigmas(cfg, "recons"))
+        assert sig.dtype == np.float32
+        out[name] = sig
+    cfg = tiny_config(num_classes=17, sigma_begin=3.0, sigma_end=0.5)
+    cfg.model.sigma_dist = "uniform"
+    out["uniform_17"] = npy(ref_get_sigmas(cfg, "unconditioned"))
+    lw = ref_ald.get_lh_weights(torch.tensor(out["mnist"]), 0.25, "linear")
+    out["lh_weights_mnist_0.25"] = npy(lw)
+    save("g06_sigmas", **out)
+
+
+def _sd(module, prefix):
+    return {prefix + "__" + k.replace(".", "__"): npy(v) for k, v in module.state_dict().items()}
+
+
+def g07_layers():
+    out = {}
+    torch.manual_seed(7)
+    act = nn.ELU()
+    x = torch.randn(2, 6, 12, 10)
+    # InstanceNorm2dPlus with perturbed beta so the bias path is visible
+    n = ref_norm.InstanceNorm2dPlus(6)
+    n.beta.data.normal_(0, 0.1)
+    out["in_x"] = npy(x)
+    out.update(_sd(n, "in"))
+    out["in_y"] = npy(n(x))
+    # ConvMeanPool 3x3 and 1x1
+    cmp3 = ref_layers.ConvMeanPool(6, 5, 3)
+    out.update(_sd(cmp3, "cmp3"))
+    out["cmp3_y"] = npy(cmp3(x))
+    # ResidualBlock: plain / plain with channel change / pooled / dilated-down / dilated-same
+    norm = ref_norm.InstanceNorm2dPlus
+    variants = {
+        "rb_plain": dict(input_dim=6, output_dim=6, resample=None),
+        "rb_widen": dict(input_dim=6, output_dim=8, resample=None),
+        "rb_pool": dict(input_dim=6, output_dim=8, resample="down"),
+        "rb_dil_down": dict(input_dim=6, output_dim=8, resample="down", dilation=2),
+        "rb_dil_same": dict(input_dim=6, output_dim=6, resample=None, dilation=4),
+    }
+    for name, kw in variants.items():
+        rb = ref_layers.ResidualBlock(act=act, normalization=norm, **kw)
+        out.update(_sd(rb, name))
+        out[name + "_y"] = npy(rb(x))
+    # RefineBlock: start / two-input (second input at half resolution) / end
+    xa = torch.randn(2, 6, 12, 10)
+    xb = torch.randn(2, 4, 6, 5)
+    out["rf_xa"], out["rf_xb"] = npy(xa), npy(xb)
+    rf = ref_layers.RefineBlock([6], 6, act=act, start=True)
+    out.update(_sd(rf, "rf_start"))
+    out["rf_start_y"] = npy(rf([xa], xa.shape[2:]))
+    rf = ref_layers.RefineBlock([6, 4], 5, act=act)
+    out.update(_sd(rf, "rf_two"))
+    out["rf_two_y"] = npy(rf([xa, xb], xa.shape[2:]))
+    rf = ref_layers.RefineBlock([6, 4], 6, act=act, end=True)
+    out.update(_sd(rf, "rf_end"))
+    out["rf_end_y"] = npy(rf([xa, xb], xa.shape[2:]))
+    # tiny NCSNv2Deepest, 32x32, 10 levels
+    cfg = tiny_config()
+    torch.manual_seed(70)
+    with quiet:
+        net = ref_ncsnv2.NCSNv2Deepest(cfg).eval()
+    for p in net.parameters():          # make biases / betas non-trivial
+        if p.ndim == 1:
+            p.data.add_(0.05 * torch.randn_like(p))
+    xin = torch.rand(3, 1, 32, 32)
+    labels = torch.tensor([0, 4, 9])
+    out.update(_sd(net, "net"))
+    out["net_x"] = npy(xin)
+    out["net_labels"] = npy(labels)
+    with torch.no_grad():
+        out["net_y"] = npy(net(xin, labels))
+    save("g07_layers", **out)
+    return net, cfg
+
+
+class _StandInSeg(nn.Module):
+    """finite-gradient stand-in for the MONAI UNet (weight is multiplied by lh_weight = 0)."""
+    def __init__(self):
+        super().__init__()
+        self.c = nn.Conv2d(1, 2, 1)
+
+    def forward(self, x):
+        return self.c(x)
+
+
+class _NoiseTape:
+    def __init__(self, seed):
+        self.g = torch.Generator().manual_seed(seed)
+        self.tape = []
+
+    def __call__(self, like):
+        n = torch.randn(like.shape, generator=self.g, dtype=like.dtype)
+        self.tape.append(npy(n))
+        return n
+
+
+def g08_ald(net, cfg):
+    out = {}
+    H = W = 32
+    ref_ald.vis_images = lambda *a, **k: None
+    ref_ald.vis_multi_channel_signal = lambda *a, **k: None
+    orig = ref_uf.RandomUndersamplingFourier._generate_mask
+    try:
+        ref_uf.RandomUndersamplingFourier._generate_mask = t1_mask_patch(MASK_PARAMS["R8"])
+        with quiet:
+            op = ref_uf.SENSE("exp", 4, 8, 0.04, (1, H, W), seed=0)
+    finally:
+        ref_uf.RandomUndersamplingFourier._generate_mask = orig
+    g = torch.Generator().manual_seed(8)
+    img = torch.complex(torch.rand(1, 1, H, W, generator=g), 0.3 * torch.randn(1, 1, H, W, generator=g))
+    B = 2
+    meas = op(img).repeat(1, B, 1, 1, 1)
+    sigmas = ref_get_sigmas(cfg, "recons")
+    params = dict(n_steps_each=3, step_lr=9e-7, denoise=True, final_only=True)
+    out["img"] = npy(img)
+    out["measurement"] = npy(meas)
+    out["sigmas"] = npy(sigmas)
+    for tag, lr_scaled in [("dc_visible", 2.0e6), ("script_default", 1.0)]:
+        tape = _NoiseTape(80)
+        real_randn_like = torch.randn_like
+        torch.randn_like = tape
+        try:
+            sampler = ref_ald.ALDInvSegProximalRealImag(
+                ref_prox.get_proximal("L2Penalty")(op), 1.0, "linear",
+                (B, 1, H, W), net, sigmas, params, cfg, meas, op, seg=_StandInSeg(), device=torch.device("cpu"))
+            with quiet:
+                res = sampler(label=torch.zeros(B, 1, H, W, dtype=torch.long), lamda=0.1, save_dir="/tmp/ipdm_oracle/out",
+                              lr_scaled=lr_scaled, seg_mode="full")[0]
+        finally:
+            torch.randn_like = real_randn_like
+            torch.set_grad_enabled(True)
+        out[f"{tag}_lr_scaled"] = np.array(lr_scaled)
+        out[f"{tag}_x"] = npy(res)
+        if tag == "dc_visible":
+            out["noise"] = np.stack(tape.tape)      # (60, B, 1, H, W): real, imag alternating per step
+    # unconditional sampler (config 1 shape family), init + noise recorded
+    tape = _NoiseTape(81)
+    real_randn_like, real_rand = torch.randn_like, torch.rand
+    gi = torch.Generator().manual_seed(82)
+    x0 = real_rand(2, 1, H, W, generator=gi)
+    torch.randn_like = tape
+    torch.rand = lambda *shape, **k: x0.clone()
+    try:
+        sampler = ref_ald.ALDUnconditionalSampler((2, 1, H, W), net, sigmas, dict(params, step_lr=2e-5), cfg,
+                                                  device=torch.device("cpu"))
+        with quiet:
+            res = sampler()[0]
+    finally:
+        torch.randn_like, torch.rand = real_randn_like, real_rand
+        torch.set_grad_enabled(True)
+    out["uncond_x0"] = npy(x0)
+    out["uncond_noise"] = np.stack(tape.tape)
+    out["uncond_step_lr"] = np.array(2e-5)
+    out["uncond_x"] = npy(res)
+    save("g08_ald", **out)
+
+
+def g09_upfirdn():
+    out = {}
+    g = torch.Generator().manual_seed(9)
+    k1 = torch.tensor([1., 3., 3., 1.])
+    k = torch.outer(k1, k1)
+    k = k / k.sum()
+    cases = {
+        "down2": dict(shape=(2, 3, 8, 8), kernel=k, up=1, down=2, pad=(1, 1)),
+        "up2": dict(shape=(2, 3, 8, 8), kernel=k * 4, up=2, down=1, pad=(2, 1)),
+        "down2_nonsq": dict(shape=(1, 2, 10, 6), kernel=k, up=1, down=2, pad=(1, 1)),
+        "up2_nonsq": dict(shape=(1, 2, 5, 9), kernel=k * 4, up=2, down=1, pad=(2, 1)),
+        "up3_down2_k5": dict(shape=(1, 2, 7, 6), kernel=torch.randn(5, 5, generator=g), up=3, down=2, pad=(3, 2)),
+        "negpad_k3": dict(shape=(1, 2, 9, 9), kernel=torch.randn(3, 3, generator=g), up=1, down=1, pad=(-1, -2)),
+        "up1_down3_k2x4": dict(shape=(2, 1, 11, 12), kernel=torch.randn(2, 4, generator=g), up=1, down=3, pad=(0, 3)),
+        "up2_down1_k6": dict(shape=(1, 1, 6, 7), kernel=torch.randn(6, 6, generator=g), up=2, down=1, pad=(4, 3)),
+    }
+    for name, c in cases.items():
+        x = torch.randn(c["shape"], generator=g)
+        out[f"{name}_x"] = npy(x)
+        out[f"{name}_k"] = npy(c["kernel"])
+        out[f"{name}_udp"] = np.array([c["up"], c["down"], c["pad"][0], c["pad"][1]], dtype=np.int64)
+        out[f"{name}_y"] = npy(ref_upfirdn.upfirdn2d(x, c["kernel"], c["up"], c["down"], c["pad"]))
+    x = torch.randn(2, 3, 8, 12, generator=g)
+    out["wrap_x"] = npy(x)
+    out["wrap_up"] = npy(ref_updown.upsample_2d(x, (1, 3, 3, 1), factor=2))
+    out["wrap_down"] = npy(ref_updown.downsample_2d(x, (1, 3, 3, 1), factor=2))
+    save("g09_upfirdn", **out)
+
+
+def g10_biasact():
+    out = {}
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 5, 4, 6, generator=g)
+    b = torch.randn(5, generator=g)
+    out["x"], out["b"] = npy(x), npy(b)
+    out["y_default"] = npy(ref_fused.fused_leaky_relu(x, b))
+    out["y_scale1.5"] = npy(ref_fused.fused_leaky_relu(x, b, 0.2, 1.5))
+    x2 = torch.randn(3, 7, generator=g)
+    b2 = torch.randn(7, generator=g)
+    out["x2"], out["b2"] = npy(x2), npy(b2)
+    out["y2"] = npy(ref_fused.fused_leaky_relu(x2, b2))
+    save("g10_biasact", **out)
+
+
+def g11_temporal():
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 5, 16, 24, generator=g)
+    f = ref_utils.reshape_temporal_dim(x, 8, 8, "forward")
+    out["x"] = npy(x)
+    out["fwd"] = npy(f)
+    out["bwd"] = npy(ref_utils.reshape_temporal_dim(f, 8, 8, "backward", img_size=(16, 24)))
+    v = torch.randn(1, 1, 6, 4, 4, generator=g)
+    fd = RefFiniteDiff(2)
+    out["fd_x"] = npy(v)
+    out["fd_fwd"] = npy(fd(v))
+    out["fd_adj"] = npy(fd.conj_op(v))
+    out["fd_tvgrad"] = npy(fd.log_lh_grad(v, lamda=0.3))
+    save("g11_temporal", **out)
+
+
+def g15_fullnet():
+    """Full-size ACDC score net on the synthetic weights the benchmark uses."""
+    from inverseproblemwithdiffusionmodel_amd.synthetic import synth_state_dict
+    cfg = tiny_config(ngf=128, num_classes=2311, sigma_begin=348, sigma_end=0.01, image_size=128)
+    with quiet:
+        net = ref_ncsnv2.NCSNv2Deepest(cfg).eval()
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=0)
+    sd["sigmas"] = net.state_dict()["sigmas"]
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(15)
+    x = torch.rand(2, 1, 128, 128, generator=g)
+    x[1] = 40.0 * torch.randn(1, 128, 128, generator=g)      # a high-noise-level input
+    labels = torch.tensor([2310, 500])
+    with torch.no_grad():
+        y = net(x, labels)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    save("g15_fullnet", x=npy(x), labels=npy(labels), y=npy(y),
+         key_names=np.array(list(shapes.keys())),
+         key_shapes=np.array([",".join(map(str, s)) for s in shapes.values()]))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or None
+    torch.set_num_threads(8)
+    steps = [("g01", g01_masks), ("g02", g02_sens), ("g03", g03_fft), ("g04", g04_g05_sense_prox),
+             ("g06", g06_sigmas), ("g09", g09_upfirdn), ("g10", g10_biasact), ("g11", g11_temporal)]
+    for tag, fn in steps:
+        if which is None or tag in which:
+            fn()
+    if which is None or "g07" in which or "g08" in which:
+        net, cfg = g07_layers()
+        g08_ald(net, cfg)
+    if which is None or "g15" in which:
+        g15_fullnet()
