@@ -1,0 +1,175 @@
+/*
+ * ipdm.h -- C ABI of libipdm.so: the MI355X (gfx950) kernels of the Annealed-Langevin-Dynamics
+ * reconstruction hot path.  Plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ * a parameter is documented as host.  All launches are asynchronous on `stream` (a hipStream_t cast
+ * to void*; NULL = the default stream), allocate nothing and never synchronise, so a caller may
+ * capture any sequence of them into a hipGraph.
+ *
+ * Return value: 0 on success; a positive hipError_t if the runtime rejected a launch; a negative
+ * IPDM_E* code if the arguments were rejected before anything was launched.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference
+ * repository root).  INTEGRATION.md shows the ctypes / pybind stub a reference maintainer would add.
+ *
+ * Layouts: images are NCHW planar, row-major, float32.  Complex data is interleaved (re, im)
+ * float32 pairs ("c64"), the memory layout of torch.complex64 / numpy.complex64.
+ */
+#ifndef IPDM_H
+#define IPDM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPDM_OK 0
+#define IPDM_EINVAL (-1)       /* bad size / NULL pointer / unsupported combination            */
+#define IPDM_EUNSUPPORTED (-2) /* valid request this build has no kernel for (size limits)     */
+
+/* activation codes used by the fused normalisation / convolution prologues */
+#define IPDM_ACT_NONE 0
+#define IPDM_ACT_ELU 1
+#define IPDM_ACT_RELU 2
+#define IPDM_ACT_LRELU02 3
+#define IPDM_ACT_SWISH 4
+
+/* library identification: returns IPDM_ABI_VERSION, writes the gfx arch string the kernels were built for */
+#define IPDM_ABI_VERSION 1
+int ipdm_abi_version(void);
+const char* ipdm_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * StyleGAN2 resampling ops (reference: op/upfirdn2d.cpp:12-23 `upfirdn2d`, kernels
+ * op/upfirdn2d_kernel.cu:49-369; op/fused_bias_act.cpp:11-21 `fused_bias_act`, kernel
+ * op/fused_bias_act_kernel.cu:19-99).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* in [major][in_h][in_w][minor] -> out [major][out_h][out_w][minor],
+ * out_h = (in_h*up_y + pad_y0 + pad_y1 - kernel_h)/down_y + 1 (likewise out_w); zero-insert upsample,
+ * pad (negative pad crops), correlate with the FLIPPED kernel, decimate.  kernel [kernel_h][kernel_w]. */
+int ipdm_upfirdn2d_f32(const float* in, const float* kernel, float* out,
+                       int major, int in_h, int in_w, int minor, int kernel_h, int kernel_w,
+                       int up_x, int up_y, int down_x, int down_y,
+                       int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
+/* y[i] = act(x[i] + b[(i / step_b) % size_b]) * scale;  act*10+grad as in the reference kernel:
+ * 10/11 linear, 12 zero, 30 leaky-relu(alpha), 31 leaky-relu gradient gated by ref, 32 zero.
+ * b == NULL or size_b == 0: no bias.  ref == NULL: treated as zeros. */
+int ipdm_fused_bias_act_f32(const float* x, const float* b, const float* ref, float* y,
+                            int64_t n, int step_b, int size_b, int act, int grad,
+                            float alpha, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * k-space operators (reference: ncsn/linear_transforms/__init__.py:36-57 i2k_complex/k2i_complex;
+ * ncsn/linear_transforms/undersampling_fourier.py:77-97 RandomUndersamplingFourier,
+ * :140-170 SENSE.__call__/conj_op/SSOS; ncsn/models/proximal_op.py:19-51 L2Penalty, :72-94 SingleCoil).
+ * mask is uint8 [mask_t][W] (1 = sampled k-space column); mask_t == 1 broadcasts over the batch,
+ * otherwise image b uses row b % mask_t (the reference's (T,1,1,W) broadcast against a (T,1,H,W) stack).
+ * sens maps are float32 [n_coils][H][W] (real, as the reference's "exp" maps).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* centred orthonormal 2-D DFT of `batch` images [H][W] c64; inverse != 0 -> k2i_complex.  Any H, W
+ * in [1, 1024]; power-of-two sizes with H*W <= 16384 take the single-launch LDS FFT. in may equal out. */
+int ipdm_fft2c_c64(const float* in, float* out, int batch, int H, int W, int inverse,
+                   float* workspace /* batch*H*W c64, only for the non-LDS path; may be NULL otherwise */,
+                   void* stream);
+/* bytes of workspace ipdm_fft2c_c64 needs for (batch,H,W); 0 when the LDS path applies */
+int64_t ipdm_fft2c_workspace_bytes(int batch, int H, int W);
+
+/* y[c][b] = mask * fft2c(S_c * x[b])        x [B][H][W] c64 -> y [n_coils][B][H][W] c64 */
+int ipdm_sense_forward_c64(const float* x, const float* sens, const uint8_t* mask, int mask_t,
+                           float* y, int B, int n_coils, int H, int W, void* stream);
+/* x[b] = sum_c S_c * ifft2c(mask? mask*s : s)    apply_mask == 0 reproduces SENSE.conj_op */
+int ipdm_sense_adjoint_c64(const float* s, const float* sens, const uint8_t* mask, int mask_t,
+                           int apply_mask, float* x, int B, int n_coils, int H, int W, void* stream);
+/* out[b] = sqrt(sum_c |ifft2c(s[c][b])|^2)    float32 [B][H][W] */
+int ipdm_sense_ssos_c64(const float* s, float* out, int B, int n_coils, int H, int W, void* stream);
+
+/* L2Penalty with a SENSE operator, closed form of its one SGD step:
+ *   x = z - coef * A^H(A z - y),   coef = 0.05 * (alpha/lamda) / (n_coils * W)  (computed by the caller)
+ * z given as planar real / imaginary float32 [B][H][W] (the sampler's x_mod_real / x_mod_imag), result
+ * written planar to out_re / out_im (may alias z_re / z_im). */
+int ipdm_sense_l2prox_f32(const float* z_re, const float* z_im, const float* y, const float* sens,
+                          const uint8_t* mask, int mask_t, float coef, float* out_re, float* out_im,
+                          float* work /* [B][H][W] c64 scratch */, int B, int n_coils, int H, int W, void* stream);
+
+/* Per-iteration scalars held in DEVICE memory, so that a captured hipGraph of one iteration can be
+ * replayed for every noise level without re-instantiation: the host (or a tiny kernel) rewrites the
+ * struct between replays. */
+typedef struct ipdm_sched_t {
+  float step;        /* step_lr * (sigma / sigma_L)^2                       */
+  float noise_scale; /* sqrt(2 * step)                                      */
+  float coef;        /* proximal coefficient (see ipdm_sense_l2prox_f32)    */
+  float sigma;       /* current noise level (informational)                 */
+  int64_t step_id;   /* global iteration counter: Philox key                */
+} ipdm_sched_t;
+
+/* One fused Annealed-Langevin iteration tail for the SENSE sampler (reference:
+ * ncsn/models/ALD_optimizers.py:238-247 + :288-327 + proximal_op.py:19-51):
+ *   x_re += step*g_re + sqrt(2*step)*n_re ; x_im likewise ; x = L2prox(x_re + i x_im)
+ * noise_re/noise_im NULL -> counter-based Philox4x32-10 normals keyed by (seed, sample id, step_id),
+ * sample id = sample_offset + b, so results do not depend on how samples are sharded over GPUs. */
+int ipdm_ald_sense_step_f32(float* x_re, float* x_im, const float* g_re, const float* g_im,
+                            const float* noise_re, const float* noise_im,
+                            float step, float noise_scale, uint64_t seed, int64_t sample_offset, int64_t step_id,
+                            const ipdm_sched_t* dev_sched /* device; non-NULL overrides step/noise_scale/coef/step_id */,
+                            const float* y, const float* sens, const uint8_t* mask, int mask_t, float coef,
+                            float* work /* [B][H][W] c64 scratch */, int B, int n_coils, int H, int W, void* stream);
+
+/* Langevin update alone (ALD_optimizers.py:117): x += step*g + noise_scale*noise ; noise NULL -> Philox. */
+int ipdm_langevin_step_f32(float* x, const float* g, const float* noise, float step, float noise_scale,
+                           uint64_t seed, int64_t sample_offset, int64_t step_id, const ipdm_sched_t* dev_sched,
+                           int64_t n_samples, int64_t sample_elems, void* stream);
+
+/* Philox normals exactly as the fused kernels draw them, for tests: out [n_samples][sample_elems] */
+int ipdm_philox_normal_f32(float* out, uint64_t seed, int64_t sample_offset, int64_t step_id, int plane,
+                           int64_t n_samples, int64_t sample_elems, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Score-network glue (reference: ncsn/models/normalization.py:150-176 InstanceNorm2dPlus;
+ * ncsn/models/layers.py:11-23 get_act, :62-83 CRPBlock max-pool, :165-184 MSFBlock bilinear sum,
+ * :291-313 ConvMeanPool mean; ncsn/models/ncsnv2.py:270-271 input rescale, :295-297 sigma division).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* per (b,c) plane statistics -> coef [B][C][3] = (mu, scale, shift) such that
+ *   InstanceNorm2dPlus(x)[b,c,:,:] = (x - mu) * scale + shift
+ * gamma/alpha/beta are the module's parameters ([C] each; beta may be NULL). Two launches. */
+int ipdm_instnorm_plus_coef_f32(const float* x, const float* alpha, const float* gamma, const float* beta,
+                                float* coef, int B, int C, int HW, void* stream);
+/* y = act((x - mu) * scale + shift) with coef from above; x may equal y */
+int ipdm_affine_act_f32(const float* x, const float* coef, float* y, int B, int C, int HW, int act, void* stream);
+/* y = act(x) elementwise */
+int ipdm_act_f32(const float* x, float* y, int64_t n, int act, void* stream);
+/* y = a*x + b (scalar a, b) */
+int ipdm_scale_shift_f32(const float* x, float* y, int64_t n, float a, float b, void* stream);
+/* out = x + y (out may alias either) */
+int ipdm_add_f32(const float* x, const float* y, float* out, int64_t n, void* stream);
+/* out[b,...] = x[b,...] * (inv ? 1/sigmas[labels[b]] : sigmas[labels[b]]^2-style scale is done by caller) */
+int ipdm_div_sigma_f32(const float* x, const float* sigmas, const int64_t* labels, float* out,
+                       int B, int64_t sample_elems, void* stream);
+/* MaxPool2d(kernel 5, stride 1, padding 2) on [planes][H][W] */
+int ipdm_maxpool5_f32(const float* x, float* y, int planes, int H, int W, void* stream);
+/* 2x2 mean pooling (ConvMeanPool's tail) [planes][H][W] -> [planes][H/2][W/2]; H, W even */
+int ipdm_meanpool2_f32(const float* x, float* y, int planes, int H, int W, void* stream);
+/* bilinear resize, align_corners=True: out (+)= resize(x); accumulate != 0 adds into out */
+int ipdm_bilinear_f32(const float* x, float* out, int planes, int in_h, int in_w, int out_h, int out_w,
+                      int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense 3x3 / 1x1 convolution, float32 MFMA implicit GEMM (reference: torch.nn.Conv2d call sites in
+ * ncsn/models/layers.py:28-60 conv1x1 / conv3x3 / dilated_conv3x3, stride 1, padding = dilation*(k/2)).
+ *   out[b,co] = bias[co] + sum_ci W[co,ci] * pre(x[b,ci])  (+ residual[b,co])
+ *   pre(v) = act((v - mu)*scale + shift) when coef != NULL (fused InstanceNorm2dPlus), else act(v)
+ * wt is the weight repacked by ipdm_conv_pack_weight_f32: [k*k][Cin][Cout].
+ * pool2 != 0 additionally applies the 2x2 mean (ConvMeanPool) in the epilogue: out is [B][Cout][H/2][W/2].
+ * ---------------------------------------------------------------------------------------------- */
+int ipdm_conv_pack_weight_f32(const float* w /* [Cout][Cin][k][k] */, float* wt, int Cout, int Cin, int k, void* stream);
+int ipdm_conv2d_f32(const float* x, const float* wt, const float* bias, const float* coef, int act,
+                    const float* residual, float* out,
+                    int B, int Cin, int Cout, int H, int W, int k, int dilation, int pool2, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPDM_H */

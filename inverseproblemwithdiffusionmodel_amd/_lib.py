@@ -1,0 +1,85 @@
+"""ctypes binding of libipdm.so (the C ABI declared in include/ipdm.h).
+
+The HIP library is the product: there is NO CPU or eager-PyTorch fallback.  Importing this module
+raises if the shared object has not been built (``python -m inverseproblemwithdiffusionmodel_amd.csrc.build``
+or ``__graft_entry__.build()``), and every op raises when handed a tensor that does not live on a GPU.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libipdm.so")
+
+P = c_void_p   # device pointer
+
+# name -> argtypes (restype is int unless listed in _RESTYPES).  Order matches include/ipdm.h.
+SIGNATURES = {
+    "ipdm_abi_version": [],
+    "ipdm_build_arch": [],
+    "ipdm_upfirdn2d_f32": [P, P, P] + [c_int] * 14 + [P],
+    "ipdm_fused_bias_act_f32": [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, P],
+    "ipdm_fft2c_c64": [P, P, c_int, c_int, c_int, c_int, P, P],
+    "ipdm_fft2c_workspace_bytes": [c_int, c_int, c_int],
+    "ipdm_sense_forward_c64": [P, P, P, c_int, P, c_int, c_int, c_int, c_int, P],
+    "ipdm_sense_adjoint_c64": [P, P, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P],
+    "ipdm_sense_ssos_c64": [P, P, c_int, c_int, c_int, c_int, P],
+    "ipdm_sense_l2prox_f32": [P, P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_int, c_int, P],
+    "ipdm_ald_sense_step_f32": [P, P, P, P, P, P, c_float, c_float, c_uint64, c_int64, c_int64, P,
+                                P, P, P, c_int, c_float, P, c_int, c_int, c_int, c_int, P],
+    "ipdm_langevin_step_f32": [P, P, P, c_float, c_float, c_uint64, c_int64, c_int64, P, c_int64, c_int64, P],
+    "ipdm_philox_normal_f32": [P, c_uint64, c_int64, c_int64, c_int, c_int64, c_int64, P],
+    "ipdm_instnorm_plus_coef_f32": [P, P, P, P, P, c_int, c_int, c_int, P],
+    "ipdm_affine_act_f32": [P, P, P, c_int, c_int, c_int, c_int, P],
+    "ipdm_act_f32": [P, P, c_int64, c_int, P],
+    "ipdm_scale_shift_f32": [P, P, c_int64, c_float, c_float, P],
+    "ipdm_add_f32": [P, P, P, c_int64, P],
+    "ipdm_div_sigma_f32": [P, P, P, P, c_int, c_int64, P],
+    "ipdm_maxpool5_f32": [P, P, c_int, c_int, c_int, P],
+    "ipdm_meanpool2_f32": [P, P, c_int, c_int, c_int, P],
+    "ipdm_bilinear_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "ipdm_conv_pack_weight_f32": [P, P, c_int, c_int, c_int, P],
+    "ipdm_conv2d_f32": [P, P, P, P, c_int, P, P] + [c_int] * 8 + [P],
+}
+_RESTYPES = {"ipdm_build_arch": c_char_p, "ipdm_fft2c_workspace_bytes": c_int64}
+
+IPDM_EINVAL = -1
+IPDM_EUNSUPPORTED = -2
+
+
+class IpdmError(RuntimeError):
+    pass
+
+
+class IpdmUnsupported(IpdmError, NotImplementedError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP kernels are not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or inverseproblemwithdiffusionmodel_amd/csrc/build.py). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the library lacks a declared entry point
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc == IPDM_EUNSUPPORTED:
+        raise IpdmUnsupported(f"{what}: no gfx950 kernel for this size/combination (IPDM_EUNSUPPORTED)")
+    if rc == IPDM_EINVAL:
+        raise IpdmError(f"{what}: invalid argument (IPDM_EINVAL)")
+    raise IpdmError(f"{what}: HIP error {rc}")
+
+
+def call(name, *args):
+    check(getattr(lib, name)(*args), name)

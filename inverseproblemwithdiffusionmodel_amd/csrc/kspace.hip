@@ -1,0 +1,485 @@
+// k-space side of the ALD step on gfx950: centred orthonormal 2-D FFT held entirely in one CU's LDS
+// (128x128 complex64 = 128 KiB of the 160 KiB), multi-coil SENSE forward / adjoint / SSOS, the
+// closed form of the reference's one-SGD-step L2Penalty proximal, and the fused Langevin + proximal
+// iteration tail.  One 1024-thread workgroup owns one image; coils are looped inside the workgroup so
+// the coil sum is deterministic (no atomics).  All of this is launch/latency-bound work (~1 MiB of
+// algorithmic traffic per sample per step) that rides beside the score network.
+//
+// The fftshift/ifftshift pairs of i2k_complex / k2i_complex (ncsn/linear_transforms/__init__.py:36-57)
+// are folded into (-1)^(r+c) sign flips before and after an ordinary FFT (exact for sizes % 4 == 0);
+// sizes the LDS path cannot take go through a direct centred DFT with an exact integer phase index.
+#include "ipdm_common.h"
+
+namespace {
+
+constexpr int FFT_THREADS = 1024;
+constexpr int FFT_MAX_ELEMS = 16384;           // 128 KiB of float2
+constexpr int FFT_EPT = FFT_MAX_ELEMS / FFT_THREADS;
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// LDS image + twiddle table.  tw[q] = exp(-2*pi*i*q/twN), twN = max(H, W).
+struct FftLds {
+  float2* buf;
+  float2* tw;
+  int twN;
+};
+
+__device__ __forceinline__ void fft_make_twiddles(const FftLds& L) {
+  for (int q = threadIdx.x; q < L.twN; q += blockDim.x) {
+    double s, c;
+    sincospi(-2.0 * (double)q / (double)L.twN, &s, &c);
+    L.tw[q] = make_float2((float)c, (float)s);
+  }
+}
+
+// One in-place Stockham stage of radix R over `nlines` lines of length N.
+//   element (line, n) lives at buf[line*ls + n*es];  lines_fast: consecutive threads -> consecutive lines.
+// Every thread reads all its butterflies, the workgroup barriers, then everyone writes.
+template <int R>
+__device__ __forceinline__ void fft_stage(const FftLds& L, int N, int Ns, int es, int ls, int nlines, bool lines_fast,
+                                          bool inverse) {
+  constexpr int BPT = FFT_EPT / R;             // butterflies per thread at the largest image
+  const int nb = N / R;                        // butterflies per line
+  const int total = nb * nlines;
+  const int twstep = L.twN / (Ns * R);
+  float2 v[BPT][R];
+  int dst[BPT];
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) {
+    int i = threadIdx.x + u * FFT_THREADS;
+    dst[u] = -1;
+    if (i < total) {
+      int line, j;
+      if (lines_fast) { j = i / nlines; line = i - j * nlines; }
+      else { line = i / nb; j = i - line * nb; }
+      int k = j & (Ns - 1);
+      int base = line * ls;
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        float2 x = L.buf[base + (j + t * nb) * es];
+        if (t > 0) {
+          float2 w = L.tw[(k * t * twstep) & (L.twN - 1)];
+          if (inverse) w.y = -w.y;
+          x = cmul(x, w);
+        }
+        v[u][t] = x;
+      }
+      dst[u] = base + (((j - k) * R) + k) * es;
+      if constexpr (R == 2) {
+        float2 a = v[u][0], b = v[u][1];
+        v[u][0] = make_float2(a.x + b.x, a.y + b.y);
+        v[u][1] = make_float2(a.x - b.x, a.y - b.y);
+      } else {
+        float2 a = v[u][0], b = v[u][1], c = v[u][2], d = v[u][3];
+        float2 apc = make_float2(a.x + c.x, a.y + c.y), amc = make_float2(a.x - c.x, a.y - c.y);
+        float2 bpd = make_float2(b.x + d.x, b.y + d.y), bmd = make_float2(b.x - d.x, b.y - d.y);
+        // forward: -i*(b-d) = (bmd.y, -bmd.x); inverse: +i*(b-d) = (-bmd.y, bmd.x)
+        float2 jb = inverse ? make_float2(-bmd.y, bmd.x) : make_float2(bmd.y, -bmd.x);
+        v[u][0] = make_float2(apc.x + bpd.x, apc.y + bpd.y);
+        v[u][1] = make_float2(amc.x + jb.x, amc.y + jb.y);
+        v[u][2] = make_float2(apc.x - bpd.x, apc.y - bpd.y);
+        v[u][3] = make_float2(amc.x - jb.x, amc.y - jb.y);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) {
+    if (dst[u] >= 0) {
+#pragma unroll
+      for (int t = 0; t < R; ++t) L.buf[dst[u] + t * Ns * es] = v[u][t];
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void fft_lines(const FftLds& L, int N, int es, int ls, int nlines, bool lines_fast,
+                                          bool inverse) {
+  int Ns = 1;
+  while (Ns * 4 <= N) {
+    fft_stage<4>(L, N, Ns, es, ls, nlines, lines_fast, inverse);
+    Ns *= 4;
+  }
+  if (Ns < N) fft_stage<2>(L, N, Ns, es, ls, nlines, lines_fast, inverse);
+}
+
+// plain (uncentred, unnormalised) 2-D FFT of buf[H][W]; caller applies the (-1)^(r+c) flips and 1/sqrt(HW).
+__device__ __forceinline__ void fft2_lds(const FftLds& L, int H, int W, bool inverse) {
+  fft_lines(L, W, 1, W, H, false, inverse);   // along rows
+  fft_lines(L, H, W, 1, W, true, inverse);    // along columns
+}
+
+__device__ __forceinline__ float sign_rc(int r, int c) { return ((r + c) & 1) ? -1.f : 1.f; }
+
+__host__ __device__ __forceinline__ bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static inline bool lds_fft_ok(int H, int W) {
+  return is_pow2(H) && is_pow2(W) && H >= 4 && W >= 4 && (int64_t)H * W <= FFT_MAX_ELEMS;
+}
+static inline size_t lds_bytes(int H, int W) { return ((size_t)H * W + (size_t)(H > W ? H : W)) * sizeof(float2); }
+
+#define FFT_LDS_SETUP(H, W)                                   \
+  extern __shared__ __align__(16) unsigned char smem_raw[];  \
+  FftLds L;                                                   \
+  L.buf = reinterpret_cast<float2*>(smem_raw);               \
+  L.tw = L.buf + (size_t)(H) * (W);                          \
+  L.twN = (H) > (W) ? (H) : (W);                             \
+  fft_make_twiddles(L);
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FFT_THREADS) void fft2c_lds_kernel(const float2* in, float2* out,
+                                                                int H, int W, int inverse) {
+  FFT_LDS_SETUP(H, W)
+  const int HW = H * W;
+  const float2* src = in + (size_t)blockIdx.x * HW;
+  float2* dst = out + (size_t)blockIdx.x * HW;
+  for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+    int r = e / W, c = e - r * W;
+    float s = sign_rc(r, c);
+    float2 v = src[e];
+    L.buf[e] = make_float2(v.x * s, v.y * s);
+  }
+  __syncthreads();
+  fft2_lds(L, H, W, inverse != 0);
+  const float scale = rsqrtf((float)HW);
+  for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+    int r = e / W, c = e - r * W;
+    float s = sign_rc(r, c) * scale;
+    float2 v = L.buf[e];
+    dst[e] = make_float2(v.x * s, v.y * s);
+  }
+}
+
+// direct centred DFT along the last axis, output transposed: in [batch][R][N] -> out [batch][N][R]
+__global__ __launch_bounds__(256) void dft_rows_transposed_kernel(const float2* __restrict__ in,
+                                                                  float2* __restrict__ out, int R, int N, int inverse) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  float2* row = reinterpret_cast<float2*>(smem_raw);
+  float2* tw = row + N;
+  const int b = blockIdx.y, r = blockIdx.x;
+  const float2* src = in + ((size_t)b * R + r) * N;
+  const double sgn = inverse ? 2.0 : -2.0;
+  const float scale = (float)(1.0 / sqrt((double)N));
+  for (int q = threadIdx.x; q < N; q += blockDim.x) {
+    double s, c;
+    sincospi(sgn * (double)q / (double)N, &s, &c);
+    tw[q] = make_float2((float)c * scale, (float)s * scale);
+    row[q] = src[q];
+  }
+  __syncthreads();
+  const int cshift = N / 2;
+  for (int k = threadIdx.x; k < N; k += blockDim.x) {
+    int dk = ((k - cshift) % N + N) % N;
+    int p = (int)(((int64_t)(N - cshift) * dk) % N);     // (m - c)(k - c) mod N at m = 0
+    float2 acc = make_float2(0.f, 0.f);
+    for (int m = 0; m < N; ++m) {
+      float2 w = tw[p], x = row[m];
+      acc.x += x.x * w.x - x.y * w.y;
+      acc.y += x.x * w.y + x.y * w.x;
+      p += dk;
+      if (p >= N) p -= N;
+    }
+    out[((size_t)b * N + k) * R + r] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool mask_at(const uint8_t* mask, int mask_t, int b, int W, int c) {
+  return mask[(size_t)(mask_t == 1 ? 0 : b % mask_t) * W + c] != 0;
+}
+
+__global__ __launch_bounds__(FFT_THREADS) void sense_forward_kernel(const float2* __restrict__ x,
+                                                                    const float* __restrict__ sens,
+                                                                    const uint8_t* __restrict__ mask, int mask_t,
+                                                                    float2* __restrict__ y, int B, int H, int W) {
+  FFT_LDS_SETUP(H, W)
+  const int HW = H * W;
+  const int b = blockIdx.x, coil = blockIdx.y;
+  const float2* src = x + (size_t)b * HW;
+  const float* sm = sens + (size_t)coil * HW;
+  for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+    int r = e / W, c = e - r * W;
+    float s = sign_rc(r, c) * sm[e];
+    float2 v = src[e];
+    L.buf[e] = make_float2(v.x * s, v.y * s);
+  }
+  __syncthreads();
+  fft2_lds(L, H, W, false);
+  const float scale = rsqrtf((float)HW);
+  float2* dst = y + ((size_t)coil * B + b) * HW;
+  for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+    int r = e / W, c = e - r * W;
+    float2 v = L.buf[e];
+    float s = mask_at(mask, mask_t, b, W, c) ? sign_rc(r, c) * scale : 0.f;
+    dst[e] = make_float2(v.x * s, v.y * s);
+  }
+}
+
+// s [n_coils][B][H][W] -> out[b] = sum_c S_c * ifft2c(s[c][b])  (or root-sum-of-squares for SSOS).
+// The coil sum is accumulated in the (L2-resident) output image, coil by coil in index order, like the
+// reference's `X_out += ...` loop: no accumulator registers live across the FFT, deterministic.
+template <bool SSOS>
+__global__ __launch_bounds__(FFT_THREADS) void sense_adjoint_kernel(const float2* __restrict__ s,
+                                                                    const float* __restrict__ sens,
+                                                                    const uint8_t* __restrict__ mask, int mask_t,
+                                                                    int apply_mask, float* out, int B,
+                                                                    int n_coils, int H, int W) {
+  FFT_LDS_SETUP(H, W)
+  const int HW = H * W;
+  const int b = blockIdx.x;
+  const float scale = rsqrtf((float)HW);
+  for (int coil = 0; coil < n_coils; ++coil) {
+    const float2* src = s + ((size_t)coil * B + b) * HW;
+    for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+      int r = e / W, c = e - r * W;
+      float sg = sign_rc(r, c);
+      if (apply_mask && !mask_at(mask, mask_t, b, W, c)) sg = 0.f;
+      float2 v = src[e];
+      L.buf[e] = make_float2(v.x * sg, v.y * sg);
+    }
+    __syncthreads();
+    fft2_lds(L, H, W, true);
+    const bool last = coil == n_coils - 1;
+    for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+      float2 v = L.buf[e];
+      size_t gi = (size_t)b * HW + e;
+      if constexpr (SSOS) {
+        float a = (v.x * v.x + v.y * v.y) * (scale * scale);
+        if (coil > 0) a += out[gi];
+        out[gi] = last ? sqrtf(a) : a;
+      } else {
+        int r = e / W, c = e - r * W;
+        float w = sign_rc(r, c) * scale * sens[(size_t)coil * HW + e];
+        float2 a = make_float2(v.x * w, v.y * w);
+        float2* o = reinterpret_cast<float2*>(out) + gi;
+        if (coil > 0) {
+          float2 prev = *o;
+          a.x += prev.x;
+          a.y += prev.y;
+        }
+        *o = a;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Langevin update (optional) + L2Penalty closed form, planar real/imag, in place.
+//   phase 0: z = x + step*g + noise_scale*n           -> stored back to x (global, L2-resident)
+//   per coil: LDS = S_c z ; FFT ; residual on sampled columns ; IFFT ; work += S_c * (.)
+//   final:   x = z - coef * work
+// `work` ([B][H][W] c64) carries the coil sum so that no accumulator registers live across the FFTs.
+template <bool LANGEVIN>
+__global__ __launch_bounds__(FFT_THREADS) void ald_sense_step_kernel(
+    float* x_re, float* x_im, const float* __restrict__ g_re, const float* __restrict__ g_im,
+    const float* __restrict__ n_re, const float* __restrict__ n_im, float step, float noise_scale, uint64_t seed,
+    int64_t sample_offset, int64_t step_id, const ipdm_sched_t* __restrict__ sched, const float2* __restrict__ y,
+    const float* __restrict__ sens, const uint8_t* __restrict__ mask, int mask_t, float coef, float2* work, int B,
+    int n_coils, int H, int W) {
+  FFT_LDS_SETUP(H, W)
+  if (sched) {
+    step = sched->step;
+    noise_scale = sched->noise_scale;
+    coef = sched->coef;
+    step_id = sched->step_id;
+  }
+  const int HW = H * W;
+  const int b = blockIdx.x;
+  const float scale = rsqrtf((float)HW);
+  float* xr = x_re + (size_t)b * HW;
+  float* xi = x_im + (size_t)b * HW;
+  float2* wk = work + (size_t)b * HW;
+  if constexpr (LANGEVIN) {
+    for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+      size_t gi = (size_t)b * HW + e;
+      float nr, ni;
+      if (n_re) {
+        nr = n_re[gi];
+        ni = n_im[gi];
+      } else {
+        float q[4];
+        const int lane4 = e & 3;
+        ipdm_philox_normal4(seed, sample_offset + b, step_id, 0, (uint32_t)(e >> 2), q);
+        nr = lane4 == 0 ? q[0] : lane4 == 1 ? q[1] : lane4 == 2 ? q[2] : q[3];
+        ipdm_philox_normal4(seed, sample_offset + b, step_id, 1, (uint32_t)(e >> 2), q);
+        ni = lane4 == 0 ? q[0] : lane4 == 1 ? q[1] : lane4 == 2 ? q[2] : q[3];
+      }
+      xr[e] = xr[e] + step * g_re[gi] + nr * noise_scale;
+      xi[e] = xi[e] + step * g_im[gi] + ni * noise_scale;
+    }
+  }
+  if (coef == 0.f) return;
+  // pass 2c: forward transform of S_c z ; pass 2c+1: inverse transform of the masked residual
+  for (int pass = 0; pass < 2 * n_coils; ++pass) {
+    const int coil = pass >> 1;
+    const bool inv = pass & 1;
+    const float* sm = sens + (size_t)coil * HW;
+    if (!inv) {
+      for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+        int r = e / W, c = e - r * W;
+        float sg = sign_rc(r, c) * sm[e];
+        L.buf[e] = make_float2(xr[e] * sg, xi[e] * sg);
+      }
+    }
+    __syncthreads();
+    fft2_lds(L, H, W, inv);
+    if (!inv) {
+      // residual on the sampled columns, re-modulated for the inverse transform:
+      //   sign*(sign*scale*v - y) = scale*v - sign*y
+      const float2* yc = y + ((size_t)coil * B + b) * HW;
+      for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+        int r = e / W, c = e - r * W;
+        float2 v = L.buf[e];
+        float2 res = make_float2(0.f, 0.f);
+        if (mask_at(mask, mask_t, b, W, c)) {
+          float sg = sign_rc(r, c);
+          float2 yy = yc[e];
+          res = make_float2(v.x * scale - sg * yy.x, v.y * scale - sg * yy.y);
+        }
+        L.buf[e] = res;
+      }
+    } else {
+      const bool last = coil == n_coils - 1;
+      for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+        int r = e / W, c = e - r * W;
+        float2 v = L.buf[e];
+        float w = sign_rc(r, c) * scale * sm[e];
+        float2 a = make_float2(v.x * w, v.y * w);
+        if (coil > 0) {
+          float2 prev = wk[e];
+          a.x += prev.x;
+          a.y += prev.y;
+        }
+        if (last) {
+          xr[e] = xr[e] - coef * a.x;
+          xi[e] = xi[e] - coef * a.y;
+        } else {
+          wk[e] = a;
+        }
+      }
+    }
+  }
+}
+
+template <typename K>
+static int set_lds_limit(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return IPDM_OK;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)bytes);
+  return e == hipSuccess ? IPDM_OK : (int)e;
+}
+
+}  // namespace
+
+extern "C" int64_t ipdm_fft2c_workspace_bytes(int batch, int H, int W) {
+  if (batch <= 0 || H <= 0 || W <= 0) return 0;
+  return lds_fft_ok(H, W) ? 0 : (int64_t)batch * H * W * 8;
+}
+
+extern "C" int ipdm_fft2c_c64(const float* in, float* out, int batch, int H, int W, int inverse, float* workspace,
+                              void* stream) {
+  IPDM_REQUIRE(batch >= 0 && H > 0 && W > 0 && H <= 1024 && W <= 1024);
+  if (batch == 0) return IPDM_OK;
+  IPDM_REQUIRE(in && out);
+  hipStream_t s = ipdm_stream(stream);
+  if (lds_fft_ok(H, W)) {
+    size_t lds = lds_bytes(H, W);
+    int rc = set_lds_limit(fft2c_lds_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fft2c_lds_kernel, dim3(batch), dim3(FFT_THREADS), lds, s, reinterpret_cast<const float2*>(in),
+                       reinterpret_cast<float2*>(out), H, W, inverse);
+    return ipdm_launch_status();
+  }
+  IPDM_REQUIRE(workspace);
+  // pass 1: DFT along W, [b][H][W] -> ws [b][W][H]; pass 2: DFT along H, ws -> out [b][H][W]
+  hipLaunchKernelGGL(dft_rows_transposed_kernel, dim3(H, batch), dim3(256), (size_t)2 * W * sizeof(float2), s,
+                     reinterpret_cast<const float2*>(in), reinterpret_cast<float2*>(workspace), H, W, inverse);
+  hipLaunchKernelGGL(dft_rows_transposed_kernel, dim3(W, batch), dim3(256), (size_t)2 * H * sizeof(float2), s,
+                     reinterpret_cast<const float2*>(workspace), reinterpret_cast<float2*>(out), W, H, inverse);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_sense_forward_c64(const float* x, const float* sens, const uint8_t* mask, int mask_t, float* y,
+                                      int B, int n_coils, int H, int W, void* stream) {
+  IPDM_REQUIRE(B >= 0 && n_coils > 0 && H > 0 && W > 0 && mask_t > 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && sens && mask && y);
+  if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
+  size_t lds = lds_bytes(H, W);
+  int rc = set_lds_limit(sense_forward_kernel, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(sense_forward_kernel, dim3(B, n_coils), dim3(FFT_THREADS), lds, ipdm_stream(stream),
+                     reinterpret_cast<const float2*>(x), sens, mask, mask_t, reinterpret_cast<float2*>(y), B, H, W);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_sense_adjoint_c64(const float* s, const float* sens, const uint8_t* mask, int mask_t,
+                                      int apply_mask, float* x, int B, int n_coils, int H, int W, void* stream) {
+  IPDM_REQUIRE(B >= 0 && n_coils > 0 && H > 0 && W > 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(s && sens && x);
+  if (apply_mask) IPDM_REQUIRE(mask && mask_t > 0);
+  if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
+  size_t lds = lds_bytes(H, W);
+  int rc = set_lds_limit(sense_adjoint_kernel<false>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(sense_adjoint_kernel<false>, dim3(B), dim3(FFT_THREADS), lds, ipdm_stream(stream),
+                     reinterpret_cast<const float2*>(s), sens, mask, mask_t > 0 ? mask_t : 1, apply_mask, x, B, n_coils,
+                     H, W);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_sense_ssos_c64(const float* s, float* out, int B, int n_coils, int H, int W, void* stream) {
+  IPDM_REQUIRE(B >= 0 && n_coils > 0 && H > 0 && W > 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(s && out);
+  if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
+  size_t lds = lds_bytes(H, W);
+  int rc = set_lds_limit(sense_adjoint_kernel<true>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(sense_adjoint_kernel<true>, dim3(B), dim3(FFT_THREADS), lds, ipdm_stream(stream),
+                     reinterpret_cast<const float2*>(s), nullptr, nullptr, 1, 0, out, B, n_coils, H, W);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_sense_l2prox_f32(const float* z_re, const float* z_im, const float* y, const float* sens,
+                                     const uint8_t* mask, int mask_t, float coef, float* out_re, float* out_im,
+                                     float* work, int B, int n_coils, int H, int W, void* stream) {
+  IPDM_REQUIRE(B >= 0 && n_coils > 0 && H > 0 && W > 0 && mask_t > 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(z_re && z_im && y && sens && mask && out_re && out_im && work);
+  if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
+  hipStream_t st = ipdm_stream(stream);
+  const size_t bytes = (size_t)B * H * W * sizeof(float);
+  if (out_re != z_re && hipMemcpyAsync(out_re, z_re, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
+  if (out_im != z_im && hipMemcpyAsync(out_im, z_im, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
+  size_t lds = lds_bytes(H, W);
+  int rc = set_lds_limit(ald_sense_step_kernel<false>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ald_sense_step_kernel<false>, dim3(B), dim3(FFT_THREADS), lds, st, out_re, out_im, nullptr,
+                     nullptr, nullptr, nullptr, 0.f, 0.f, 0ull, 0ll, 0ll, nullptr, reinterpret_cast<const float2*>(y), sens,
+                     mask, mask_t, coef, reinterpret_cast<float2*>(work), B, n_coils, H, W);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_ald_sense_step_f32(float* x_re, float* x_im, const float* g_re, const float* g_im,
+                                       const float* noise_re, const float* noise_im, float step, float noise_scale,
+                                       uint64_t seed, int64_t sample_offset, int64_t step_id,
+                                       const ipdm_sched_t* dev_sched, const float* y, const float* sens, const uint8_t* mask, int mask_t, float coef, float* work,
+                                       int B, int n_coils, int H, int W, void* stream) {
+  IPDM_REQUIRE(B >= 0 && n_coils > 0 && H > 0 && W > 0 && mask_t > 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x_re && x_im && g_re && g_im && y && sens && mask && work);
+  IPDM_REQUIRE((noise_re == nullptr) == (noise_im == nullptr));
+  if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
+  size_t lds = lds_bytes(H, W);
+  int rc = set_lds_limit(ald_sense_step_kernel<true>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ald_sense_step_kernel<true>, dim3(B), dim3(FFT_THREADS), lds, ipdm_stream(stream), x_re, x_im,
+                     g_re, g_im, noise_re, noise_im, step, noise_scale, seed, (long long)sample_offset,
+                     (long long)step_id, dev_sched, reinterpret_cast<const float2*>(y), sens, mask, mask_t, coef,
+                     reinterpret_cast<float2*>(work), B, n_coils, H, W);
+  return ipdm_launch_status();
+}

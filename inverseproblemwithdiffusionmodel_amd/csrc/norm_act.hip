@@ -1,0 +1,333 @@
+// Score-network glue kernels for gfx950: InstanceNorm++ statistics -> per-(image, channel) affine
+// coefficients, fused affine+activation, element-wise helpers, 5x5 max-pool, 2x2 mean-pool and
+// align_corners bilinear resize(+accumulate).  All HBM/L2-bound, NCHW planar float32.
+//
+// Reference semantics: ncsn/models/normalization.py:150-176 (InstanceNorm2dPlus),
+// ncsn/models/layers.py:11-23 (activations), :62-83 (CRPBlock MaxPool2d(5,1,2)), :165-184 (MSFBlock
+// F.interpolate bilinear align_corners=True), :309-313 (ConvMeanPool mean), ncsnv2.py:270-271,295-297.
+#include "ipdm_common.h"
+
+namespace {
+
+// ---- InstanceNorm++ ---------------------------------------------------------------------------
+// pass 1: one workgroup per (b, c) plane: mean and 1/sqrt(biased var + 1e-5), two sweeps (2nd is L2-hot)
+__global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restrict__ x, float* __restrict__ coef,
+                                                          int HW) {
+  __shared__ double red[4];
+  const float* p = x + (size_t)blockIdx.x * HW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+  float s = 0.f;
+  if (vec) {
+    for (int i = tid; i < HW / 4; i += 256) {
+      float4 v = reinterpret_cast<const float4*>(p)[i];
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (int i = tid; i < HW; i += 256) s += p[i];
+  }
+  double ds = ipdm_wave_sum((double)s);
+  if (lane == 0) red[wave] = ds;
+  __syncthreads();
+  const float mean = (float)((red[0] + red[1] + red[2] + red[3]) / (double)HW);
+  __syncthreads();
+  float q = 0.f;
+  if (vec) {
+    for (int i = tid; i < HW / 4; i += 256) {
+      float4 v = reinterpret_cast<const float4*>(p)[i];
+      float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  } else {
+    for (int i = tid; i < HW; i += 256) {
+      float a = p[i] - mean;
+      q += a * a;
+    }
+  }
+  double dq = ipdm_wave_sum((double)q);
+  if (lane == 0) red[wave] = dq;
+  __syncthreads();
+  if (tid == 0) {
+    float var = (float)((red[0] + red[1] + red[2] + red[3]) / (double)HW);
+    coef[(size_t)blockIdx.x * 3 + 0] = mean;
+    coef[(size_t)blockIdx.x * 3 + 1] = 1.0f / sqrtf(var + 1e-5f);
+  }
+}
+
+// pass 2: one workgroup per image: cross-channel mean / unbiased variance of the plane means, then
+// coef[b][c] = (mu, gamma*rstd, beta + gamma*alpha*(mu - m)/sqrt(v + 1e-5))
+__global__ __launch_bounds__(256) void instnorm_plus_coef_kernel(float* __restrict__ coef,
+                                                                 const float* __restrict__ alpha,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int C) {
+  __shared__ double red[4];
+  float* cb = coef + (size_t)blockIdx.x * C * 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double s = 0.0;
+  for (int c = tid; c < C; c += 256) s += (double)cb[c * 3];
+  s = ipdm_wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float m = (float)((red[0] + red[1] + red[2] + red[3]) / (double)C);
+  __syncthreads();
+  double q = 0.0;
+  for (int c = tid; c < C; c += 256) {
+    double d = (double)cb[c * 3] - (double)m;
+    q += d * d;
+  }
+  q = ipdm_wave_sum(q);
+  if (lane == 0) red[wave] = q;
+  __syncthreads();
+  const float v = (float)((red[0] + red[1] + red[2] + red[3]) / (double)(C - 1));   // C == 1 -> NaN, as torch.var
+  const float inv = 1.0f / sqrtf(v + 1e-5f);
+  for (int c = tid; c < C; c += 256) {
+    float mu = cb[c * 3], rstd = cb[c * 3 + 1];
+    float g = gamma[c];
+    float mn = (mu - m) * inv;
+    cb[c * 3 + 1] = g * rstd;
+    cb[c * 3 + 2] = (beta ? beta[c] : 0.f) + g * (mn * alpha[c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* x, const float* __restrict__ coef, float* y,
+                                                         int HW, int act) {
+  // grid.x = plane tiles, grid.y = planes
+  const size_t plane = blockIdx.y;
+  const float mu = coef[plane * 3], sc = coef[plane * 3 + 1], sh = coef[plane * 3 + 2];
+  const float* p = x + plane * HW;
+  float* o = y + plane * HW;
+  if ((HW & 3) == 0) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW / 4; i += gridDim.x * 256) {
+      float4 v = reinterpret_cast<const float4*>(p)[i];
+      v.x = ipdm_act((v.x - mu) * sc + sh, act);
+      v.y = ipdm_act((v.y - mu) * sc + sh, act);
+      v.z = ipdm_act((v.z - mu) * sc + sh, act);
+      v.w = ipdm_act((v.w - mu) * sc + sh, act);
+      reinterpret_cast<float4*>(o)[i] = v;
+    }
+  } else {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) o[i] = ipdm_act((p[i] - mu) * sc + sh, act);
+  }
+}
+
+// ---- generic element-wise -------------------------------------------------------------------
+template <typename F>
+__global__ __launch_bounds__(256) void ew1_kernel(const float* x, float* y, int64_t n, F f) {
+  const int64_t nv = n / 4;
+  const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  if (vec) {
+    for (int64_t i = tid; i < nv; i += stride) {
+      float4 v = reinterpret_cast<const float4*>(x)[i];
+      v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
+      reinterpret_cast<float4*>(y)[i] = v;
+    }
+    for (int64_t i = nv * 4 + tid; i < n; i += stride) y[i] = f(x[i]);
+  } else {
+    for (int64_t i = tid; i < n; i += stride) y[i] = f(x[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* x, const float* y, float* out, int64_t n) {
+  const int64_t nv = n / 4;
+  const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  if (vec) {
+    for (int64_t i = tid; i < nv; i += stride) {
+      float4 a = reinterpret_cast<const float4*>(x)[i], b = reinterpret_cast<const float4*>(y)[i];
+      reinterpret_cast<float4*>(out)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    for (int64_t i = nv * 4 + tid; i < n; i += stride) out[i] = x[i] + y[i];
+  } else {
+    for (int64_t i = tid; i < n; i += stride) out[i] = x[i] + y[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void div_sigma_kernel(const float* x, const float* __restrict__ sigmas,
+                                                        const int64_t* __restrict__ labels, float* out,
+                                                        int64_t sample_elems) {
+  const float sg = sigmas[labels[blockIdx.y]];
+  const float* p = x + (size_t)blockIdx.y * sample_elems;
+  float* o = out + (size_t)blockIdx.y * sample_elems;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < sample_elems; i += (int64_t)gridDim.x * 256) o[i] = p[i] / sg;
+}
+
+// ---- pooling / resize -------------------------------------------------------------------------
+constexpr int MP_T = 32;
+__global__ __launch_bounds__(256) void maxpool5_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W) {
+  __shared__ float tile[MP_T + 4][MP_T + 4 + 1];
+  __shared__ float rowmax[MP_T + 4][MP_T + 1];
+  const int tiles_x = (W + MP_T - 1) / MP_T;
+  const int ty0 = (blockIdx.x / tiles_x) * MP_T, tx0 = (blockIdx.x % tiles_x) * MP_T;
+  const float* p = x + (size_t)blockIdx.y * H * W;
+  float* o = y + (size_t)blockIdx.y * H * W;
+  for (int i = threadIdx.x; i < (MP_T + 4) * (MP_T + 4); i += 256) {
+    int r = i / (MP_T + 4), c = i % (MP_T + 4);
+    int gy = ty0 + r - 2, gx = tx0 + c - 2;
+    tile[r][c] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? p[(size_t)gy * W + gx] : -INFINITY;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (MP_T + 4) * MP_T; i += 256) {
+    int r = i / MP_T, c = i % MP_T;
+    float m = fmaxf(fmaxf(tile[r][c], tile[r][c + 1]), fmaxf(tile[r][c + 2], tile[r][c + 3]));
+    rowmax[r][c] = fmaxf(m, tile[r][c + 4]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < MP_T * MP_T; i += 256) {
+    int r = i / MP_T, c = i % MP_T;
+    int gy = ty0 + r, gx = tx0 + c;
+    if (gy < H && gx < W) {
+      float m = fmaxf(fmaxf(rowmax[r][c], rowmax[r + 1][c]), fmaxf(rowmax[r + 2][c], rowmax[r + 3][c]));
+      o[(size_t)gy * W + gx] = fmaxf(m, rowmax[r + 4][c]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void meanpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n_out,
+                                                        int H, int W) {
+  const int OH = H / 2, OW = W / 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * 256) {
+    int ox = (int)(i % OW);
+    int64_t t = i / OW;
+    int oy = (int)(t % OH);
+    int64_t plane = t / OH;
+    const float* p = x + (plane * H + 2 * oy) * (int64_t)W + 2 * ox;
+    float2 top = *reinterpret_cast<const float2*>(p);
+    float2 bot = *reinterpret_cast<const float2*>(p + W);
+    y[i] = (((top.x + bot.x) + top.y) + bot.y) / 4.0f;     // the reference's summation order
+  }
+}
+
+__global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ x, float* out, int64_t n_out, int ih,
+                                                       int iw, int oh, int ow, float sh, float sw, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * 256) {
+    int ox = (int)(i % ow);
+    int64_t t = i / ow;
+    int oy = (int)(t % oh);
+    int64_t plane = t / oh;
+    float fy = sh * oy, fx = sw * ox;
+    int y0 = (int)fy, x0 = (int)fx;
+    int yp = y0 < ih - 1 ? 1 : 0, xp = x0 < iw - 1 ? 1 : 0;
+    float ly1 = fy - y0, lx1 = fx - x0;
+    float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const float* p = x + plane * (int64_t)ih * iw;
+    float v = ly0 * (lx0 * p[y0 * iw + x0] + lx1 * p[y0 * iw + x0 + xp]) +
+              ly1 * (lx0 * p[(y0 + yp) * iw + x0] + lx1 * p[(y0 + yp) * iw + x0 + xp]);
+    out[i] = accumulate ? out[i] + v : v;
+  }
+}
+
+struct ActOp {
+  int act;
+  __device__ float operator()(float v) const { return ipdm_act(v, act); }
+};
+struct ScaleShiftOp {
+  float a, b;
+  __device__ float operator()(float v) const { return a * v + b; }
+};
+
+}  // namespace
+
+extern "C" int ipdm_instnorm_plus_coef_f32(const float* x, const float* alpha, const float* gamma, const float* beta,
+                                           float* coef, int B, int C, int HW, void* stream) {
+  IPDM_REQUIRE(B >= 0 && C > 0 && HW > 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && alpha && gamma && coef);
+  hipStream_t s = ipdm_stream(stream);
+  hipLaunchKernelGGL(plane_stats_kernel, dim3(B * C), dim3(256), 0, s, x, coef, HW);
+  hipLaunchKernelGGL(instnorm_plus_coef_kernel, dim3(B), dim3(256), 0, s, coef, alpha, gamma, beta, C);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_affine_act_f32(const float* x, const float* coef, float* y, int B, int C, int HW, int act,
+                                   void* stream) {
+  IPDM_REQUIRE(B >= 0 && C > 0 && HW > 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && coef && y);
+  IPDM_REQUIRE((int64_t)B * C <= 65535 * 32);
+  int gx = (HW / 4 + 255) / 256;
+  if (gx < 1) gx = 1;
+  if (gx > 64) gx = 64;
+  int64_t planes = (int64_t)B * C;
+  // gridDim.y is limited to 65535: fold planes in chunks
+  for (int64_t p0 = 0; p0 < planes; p0 += 65535) {
+    int np = (int)((planes - p0) < 65535 ? (planes - p0) : 65535);
+    hipLaunchKernelGGL(affine_act_kernel, dim3(gx, np), dim3(256), 0, ipdm_stream(stream), x + p0 * HW, coef + p0 * 3,
+                       y + p0 * HW, HW, act);
+  }
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_act_f32(const float* x, float* y, int64_t n, int act, void* stream) {
+  IPDM_REQUIRE(n >= 0);
+  if (n == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && y);
+  hipLaunchKernelGGL(ew1_kernel<ActOp>, dim3(ipdm_ew_grid(n / 4 + 1, 256)), dim3(256), 0, ipdm_stream(stream), x, y, n,
+                     ActOp{act});
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_scale_shift_f32(const float* x, float* y, int64_t n, float a, float b, void* stream) {
+  IPDM_REQUIRE(n >= 0);
+  if (n == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && y);
+  hipLaunchKernelGGL(ew1_kernel<ScaleShiftOp>, dim3(ipdm_ew_grid(n / 4 + 1, 256)), dim3(256), 0, ipdm_stream(stream), x,
+                     y, n, ScaleShiftOp{a, b});
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_add_f32(const float* x, const float* y, float* out, int64_t n, void* stream) {
+  IPDM_REQUIRE(n >= 0);
+  if (n == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && y && out);
+  hipLaunchKernelGGL(add_kernel, dim3(ipdm_ew_grid(n / 4 + 1, 256)), dim3(256), 0, ipdm_stream(stream), x, y, out, n);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_div_sigma_f32(const float* x, const float* sigmas, const int64_t* labels, float* out, int B,
+                                  int64_t sample_elems, void* stream) {
+  IPDM_REQUIRE(B >= 0 && sample_elems >= 0 && B <= 65535);
+  if (B == 0 || sample_elems == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && sigmas && labels && out);
+  int gx = (int)((sample_elems + 255) / 256);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(div_sigma_kernel, dim3(gx, B), dim3(256), 0, ipdm_stream(stream), x, sigmas, labels, out,
+                     (long long)sample_elems);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_maxpool5_f32(const float* x, float* y, int planes, int H, int W, void* stream) {
+  IPDM_REQUIRE(planes >= 0 && H > 0 && W > 0);
+  if (planes == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && y && x != y);
+  int tiles = ((H + MP_T - 1) / MP_T) * ((W + MP_T - 1) / MP_T);
+  for (int p0 = 0; p0 < planes; p0 += 65535) {
+    int np = (planes - p0) < 65535 ? (planes - p0) : 65535;
+    hipLaunchKernelGGL(maxpool5_kernel, dim3(tiles, np), dim3(256), 0, ipdm_stream(stream), x + (size_t)p0 * H * W,
+                       y + (size_t)p0 * H * W, H, W);
+  }
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_meanpool2_f32(const float* x, float* y, int planes, int H, int W, void* stream) {
+  IPDM_REQUIRE(planes >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0);
+  if (planes == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && y);
+  int64_t n_out = (int64_t)planes * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(meanpool2_kernel, dim3(ipdm_ew_grid(n_out, 256)), dim3(256), 0, ipdm_stream(stream), x, y,
+                     (long long)n_out, H, W);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_bilinear_f32(const float* x, float* out, int planes, int in_h, int in_w, int out_h, int out_w,
+                                 int accumulate, void* stream) {
+  IPDM_REQUIRE(planes >= 0 && in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0);
+  if (planes == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && out);
+  float sh = out_h > 1 ? (float)(in_h - 1) / (float)(out_h - 1) : 0.f;
+  float sw = out_w > 1 ? (float)(in_w - 1) / (float)(out_w - 1) : 0.f;
+  int64_t n_out = (int64_t)planes * out_h * out_w;
+  hipLaunchKernelGGL(bilinear_kernel, dim3(ipdm_ew_grid(n_out, 256)), dim3(256), 0, ipdm_stream(stream), x, out,
+                     (long long)n_out, in_h, in_w, out_h, out_w, sh, sw, accumulate);
+  return ipdm_launch_status();
+}

@@ -1,0 +1,261 @@
+"""torch-tensor front end of the libipdm.so kernels: device memory, shapes and streams come from
+PyTorch-ROCm (plumbing), all arithmetic happens in the hand-written HIP kernels (csrc/).
+
+Every function requires GPU tensors and raises otherwise -- there is no CPU path.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, P
+
+ACT_NONE, ACT_ELU, ACT_RELU, ACT_LRELU02, ACT_SWISH = 0, 1, 2, 3, 4
+ACT_CODES = {"none": ACT_NONE, None: ACT_NONE, "elu": ACT_ELU, "relu": ACT_RELU, "lrelu": ACT_LRELU02,
+             "swish": ACT_SWISH}
+
+
+def _gpu(t, dtype=None, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"ipdm: {name} must be a GPU tensor (the HIP path has no CPU fallback); got "
+                           f"{getattr(t, 'device', type(t))}")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"ipdm: {name} must be {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t):
+    return P(t.data_ptr()) if t is not None else P(0)
+
+
+def _stream():
+    return P(torch.cuda.current_stream().cuda_stream)
+
+
+def _c64_as_f32(t):
+    return torch.view_as_real(t)
+
+
+# ---- StyleGAN2 ops -----------------------------------------------------------------------------
+def upfirdn2d_raw(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
+    """x [major, in_h, in_w, minor] -> [major, out_h, out_w, minor] (the reference extension's signature)."""
+    x = _gpu(x, torch.float32, "input")
+    kernel = _gpu(kernel, torch.float32, "kernel")
+    major, in_h, in_w, minor = x.shape
+    kh, kw = kernel.shape
+    out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) // down_y + 1
+    out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) // down_x + 1
+    out = torch.empty((major, out_h, out_w, minor), dtype=torch.float32, device=x.device)
+    call("ipdm_upfirdn2d_f32", _ptr(x), _ptr(kernel), _ptr(out), major, in_h, in_w, minor, kh, kw,
+         up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, _stream())
+    return out
+
+
+def fused_bias_act_raw(x, bias, ref, act, grad, alpha, scale):
+    x = _gpu(x, torch.float32, "input")
+    bias = None if bias is None or bias.numel() == 0 else _gpu(bias, torch.float32, "bias")
+    ref = None if ref is None or ref.numel() == 0 else _gpu(ref, torch.float32, "refer")
+    step_b = 1
+    for s in x.shape[2:]:
+        step_b *= s
+    y = torch.empty_like(x)
+    call("ipdm_fused_bias_act_f32", _ptr(x), _ptr(bias), _ptr(ref), _ptr(y), x.numel(), step_b,
+         0 if bias is None else bias.numel(), act, grad, float(alpha), float(scale), _stream())
+    return y
+
+
+# ---- k-space --------------------------------------------------------------------------------
+def fft2c(x, inverse=False):
+    x = _gpu(x, name="input")
+    if x.dtype != torch.complex64:
+        x = x.to(torch.complex64)
+    H, W = x.shape[-2:]
+    batch = x.numel() // (H * W) if H * W else 0
+    out = torch.empty_like(x)
+    ws_bytes = _lib.lib.ipdm_fft2c_workspace_bytes(batch, H, W)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
+    call("ipdm_fft2c_c64", _ptr(x), _ptr(out), batch, H, W, int(bool(inverse)), _ptr(ws), _stream())
+    return out
+
+
+def _mask_u8(mask, W, device):
+    """bool/any mask broadcastable over (..., W) -> uint8 [mask_t, W]."""
+    m = mask.to(device=device)
+    if m.shape[-1] != W:
+        raise ValueError(f"mask last dim {m.shape[-1]} != W {W}")
+    m = m.reshape(-1, W)
+    return (m != 0).to(torch.uint8).contiguous()
+
+
+def sense_forward(x, sens_f32, mask_u8):
+    x = _gpu(x, torch.complex64, "x")
+    B = x.numel() // (x.shape[-1] * x.shape[-2])
+    H, W = x.shape[-2:]
+    n = sens_f32.shape[0]
+    y = torch.empty((n,) + tuple(x.shape), dtype=torch.complex64, device=x.device)
+    call("ipdm_sense_forward_c64", _ptr(x), _ptr(sens_f32), _ptr(mask_u8), mask_u8.shape[0], _ptr(y), B, n, H, W,
+         _stream())
+    return y
+
+
+def sense_adjoint(s, sens_f32, mask_u8=None, apply_mask=False):
+    s = _gpu(s, torch.complex64, "s")
+    n = s.shape[0]
+    H, W = s.shape[-2:]
+    B = s[0].numel() // (H * W)
+    x = torch.empty(tuple(s.shape[1:]), dtype=torch.complex64, device=s.device)
+    call("ipdm_sense_adjoint_c64", _ptr(s), _ptr(sens_f32), _ptr(mask_u8), 1 if mask_u8 is None else mask_u8.shape[0],
+         int(bool(apply_mask)), _ptr(x), B, n, H, W, _stream())
+    return x
+
+
+def sense_ssos(s):
+    s = _gpu(s, torch.complex64, "s")
+    n = s.shape[0]
+    H, W = s.shape[-2:]
+    B = s[0].numel() // (H * W)
+    out = torch.empty(tuple(s.shape[1:]), dtype=torch.float32, device=s.device)
+    call("ipdm_sense_ssos_c64", _ptr(s), _ptr(out), B, n, H, W, _stream())
+    return out
+
+
+def sense_l2prox(z_re, z_im, y, sens_f32, mask_u8, coef, out_re=None, out_im=None, work=None):
+    z_re, z_im = _gpu(z_re, torch.float32, "z_re"), _gpu(z_im, torch.float32, "z_im")
+    y = _gpu(y, torch.complex64, "y")
+    H, W = z_re.shape[-2:]
+    B = z_re.numel() // (H * W)
+    out_re = torch.empty_like(z_re) if out_re is None else out_re
+    out_im = torch.empty_like(z_im) if out_im is None else out_im
+    work = torch.empty(B * H * W * 2, dtype=torch.float32, device=z_re.device) if work is None else work
+    call("ipdm_sense_l2prox_f32", _ptr(z_re), _ptr(z_im), _ptr(y), _ptr(sens_f32), _ptr(mask_u8), mask_u8.shape[0],
+         float(coef), _ptr(out_re), _ptr(out_im), _ptr(work), B, sens_f32.shape[0], H, W, _stream())
+    return out_re, out_im
+
+
+def ald_sense_step(x_re, x_im, g_re, g_im, y, sens_f32, mask_u8, work, step=0.0, noise_scale=0.0, coef=0.0,
+                   noise_re=None, noise_im=None, seed=0, sample_offset=0, step_id=0, dev_sched=None):
+    """in place on x_re / x_im.  dev_sched: uint8/any device tensor holding an ipdm_sched_t."""
+    H, W = x_re.shape[-2:]
+    B = x_re.numel() // (H * W)
+    call("ipdm_ald_sense_step_f32", _ptr(x_re), _ptr(x_im), _ptr(g_re), _ptr(g_im), _ptr(noise_re), _ptr(noise_im),
+         float(step), float(noise_scale), int(seed), int(sample_offset), int(step_id), _ptr(dev_sched),
+         _ptr(y), _ptr(sens_f32), _ptr(mask_u8), mask_u8.shape[0], float(coef), _ptr(work), B, sens_f32.shape[0], H, W,
+         _stream())
+
+
+def langevin_step(x, g, step=0.0, noise_scale=0.0, noise=None, seed=0, sample_offset=0, step_id=0, dev_sched=None):
+    """x += step*g + noise_scale*noise in place; x [n_samples, ...]."""
+    x = _gpu(x, torch.float32, "x")
+    n_samples = x.shape[0]
+    call("ipdm_langevin_step_f32", _ptr(x), _ptr(g), _ptr(noise), float(step), float(noise_scale), int(seed),
+         int(sample_offset), int(step_id), _ptr(dev_sched), n_samples, x.numel() // max(n_samples, 1), _stream())
+    return x
+
+
+def philox_normal(shape, device, seed=0, sample_offset=0, step_id=0, plane=0):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    n_samples = shape[0]
+    call("ipdm_philox_normal_f32", _ptr(out), int(seed), int(sample_offset), int(step_id), int(plane), n_samples,
+         out.numel() // max(n_samples, 1), _stream())
+    return out
+
+
+# ---- score-network glue -----------------------------------------------------------------------
+def instnorm_plus_coef(x, alpha, gamma, beta):
+    x = _gpu(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    coef = torch.empty((B, C, 3), dtype=torch.float32, device=x.device)
+    call("ipdm_instnorm_plus_coef_f32", _ptr(x), _ptr(alpha), _ptr(gamma), _ptr(beta), _ptr(coef), B, C, H * W,
+         _stream())
+    return coef
+
+
+def affine_act(x, coef, act=ACT_NONE, out=None):
+    x = _gpu(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    out = torch.empty_like(x) if out is None else out
+    call("ipdm_affine_act_f32", _ptr(x), _ptr(coef), _ptr(out), B, C, H * W, act, _stream())
+    return out
+
+
+def act(x, code, out=None):
+    x = _gpu(x, torch.float32, "x")
+    out = torch.empty_like(x) if out is None else out
+    call("ipdm_act_f32", _ptr(x), _ptr(out), x.numel(), code, _stream())
+    return out
+
+
+def scale_shift(x, a, b, out=None):
+    x = _gpu(x, torch.float32, "x")
+    out = torch.empty_like(x) if out is None else out
+    call("ipdm_scale_shift_f32", _ptr(x), _ptr(out), x.numel(), float(a), float(b), _stream())
+    return out
+
+
+def add(x, y, out=None):
+    x, y = _gpu(x, torch.float32, "x"), _gpu(y, torch.float32, "y")
+    if x.shape != y.shape:
+        raise ValueError(f"ipdm add: shapes differ {tuple(x.shape)} vs {tuple(y.shape)}")
+    out = torch.empty_like(x) if out is None else out
+    call("ipdm_add_f32", _ptr(x), _ptr(y), _ptr(out), x.numel(), _stream())
+    return out
+
+
+def div_sigma(x, sigmas, labels, out=None):
+    x = _gpu(x, torch.float32, "x")
+    labels = _gpu(labels, torch.int64, "labels")
+    out = torch.empty_like(x) if out is None else out
+    B = x.shape[0]
+    call("ipdm_div_sigma_f32", _ptr(x), _ptr(sigmas), _ptr(labels), _ptr(out), B, x.numel() // max(B, 1), _stream())
+    return out
+
+
+def maxpool5(x):
+    x = _gpu(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    call("ipdm_maxpool5_f32", _ptr(x), _ptr(out), B * C, H, W, _stream())
+    return out
+
+
+def meanpool2(x):
+    x = _gpu(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    out = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    call("ipdm_meanpool2_f32", _ptr(x), _ptr(out), B * C, H, W, _stream())
+    return out
+
+
+def bilinear(x, size, out=None, accumulate=False):
+    x = _gpu(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    oh, ow = int(size[0]), int(size[1])
+    if out is None:
+        out = torch.empty((B, C, oh, ow), dtype=torch.float32, device=x.device)
+        accumulate = False
+    call("ipdm_bilinear_f32", _ptr(x), _ptr(out), B * C, H, W, oh, ow, int(bool(accumulate)), _stream())
+    return out
+
+
+# ---- convolution ------------------------------------------------------------------------------
+def conv_pack_weight(w):
+    w = _gpu(w, torch.float32, "weight")
+    Cout, Cin, k, k2 = w.shape
+    assert k == k2
+    wt = torch.empty((k * k, Cin, Cout), dtype=torch.float32, device=w.device)
+    call("ipdm_conv_pack_weight_f32", _ptr(w), _ptr(wt), Cout, Cin, k, _stream())
+    return wt
+
+
+def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, pool2=False, out=None):
+    """x [B,Cin,H,W]; wt packed [k*k,Cin,Cout]; optional fused InstanceNorm++ coefficients / activation on the
+    input, bias, residual add and 2x2 mean-pool on the output."""
+    x = _gpu(x, torch.float32, "x")
+    B, Cin, H, W = x.shape
+    kk, Cin_w, Cout = wt.shape
+    if Cin_w != Cin:
+        raise ValueError(f"conv2d: weight Cin {Cin_w} != input Cin {Cin}")
+    k = {1: 1, 9: 3}[kk]
+    oh, ow = (H // 2, W // 2) if pool2 else (H, W)
+    out = torch.empty((B, Cout, oh, ow), dtype=torch.float32, device=x.device) if out is None else out
+    call("ipdm_conv2d_f32", _ptr(x), _ptr(wt), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
+         B, Cin, Cout, H, W, k, dilation, int(bool(pool2)), _stream())
+    return out

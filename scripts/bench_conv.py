@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Micro-benchmark: the hand-written fp32 MFMA convolution vs MIOpen (torch.nn.functional.conv2d) on
+the layer shapes of NCSNv2Deepest at 128x128 (SURVEY.md 3.5 conv census).  GPU only."""
+import sys
+import os
+import time
+import torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from inverseproblemwithdiffusionmodel_amd import ops
+
+B = int(os.environ.get("BENCH_B", 28))
+SHAPES = [  # (count per forward, Cin, Cout, H, dil)
+    (18, 128, 128, 128, 1), (9, 128, 128, 64, 1), (8, 256, 256, 64, 1), (17, 256, 256, 32, 1),
+    (25, 256, 256, 16, 1), (16, 512, 512, 16, 2), (5, 512, 512, 16, 4), (1, 128, 256, 128, 1),
+    (1, 256, 512, 16, 2), (1, 1, 128, 128, 1), (1, 128, 1, 128, 1),
+]
+
+
+def timeit(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+tot_m = tot_o = 0.0
+print(f"B={B}  (fp32 MFMA peak 157.3 TFLOP/s)")
+for cnt, ci, co, hw, dil in SHAPES:
+    x = torch.randn(B, ci, hw, hw, device="cuda")
+    w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
+    bias = torch.randn(co, device="cuda")
+    wt = ops.conv_pack_weight(w)
+    out = torch.empty(B, co, hw, hw, device="cuda")
+    flop = 2.0 * B * hw * hw * ci * co * 9
+    t_m = timeit(lambda: F.conv2d(x, w, bias, padding=dil, dilation=dil))
+    t_o = timeit(lambda: ops.conv2d(x, wt, bias, dilation=dil, out=out))
+    err = (out - F.conv2d(x, w, bias, padding=dil, dilation=dil)).abs().max().item()
+    tot_m += cnt * t_m; tot_o += cnt * t_o
+    print(f"{cnt:3d}x {ci:4d}->{co:4d} @{hw:3d}^2 d{dil}: miopen {t_m:8.3f} ms {flop / t_m / 1e9:7.1f} TF | "
+          f"ipdm {t_o:8.3f} ms {flop / t_o / 1e9:7.1f} TF | maxdiff {err:.2e}", flush=True)
+print(f"weighted total per forward: miopen {tot_m:.1f} ms, ipdm {tot_o:.1f} ms")

@@ -1,0 +1,334 @@
+"""Parity of the individual HIP kernels (through the C ABI, via ops.py) against the CPU oracle and
+the golden fixtures.  Tolerances are fp32 round-off (stated per test); integer/index logic is exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import state_dict_from_golden
+from oracle import kspace, resample, scorenet
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from inverseproblemwithdiffusionmodel_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def test_cpu_tensor_is_rejected(ops):
+    with pytest.raises(RuntimeError):
+        ops.act(torch.zeros(4), ops.ACT_ELU)
+
+
+# ---- upfirdn2d / bias-act ---------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["down2", "up2", "down2_nonsq", "up2_nonsq", "up3_down2_k5", "negpad_k3",
+                                  "up1_down3_k2x4", "up2_down1_k6"])
+def test_upfirdn2d_golden(ops, golden, name):
+    g = golden("g09_upfirdn")
+    x, k = g[f"{name}_x"], g[f"{name}_k"]
+    up, down, p0, p1 = (int(v) for v in g[f"{name}_udp"])
+    N, C, H, W = x.shape
+    y = ops.upfirdn2d_raw(dev(x).reshape(N * C, H, W, 1), dev(k), up, up, down, down, p0, p1, p0, p1)
+    y = y.reshape(N, C, y.shape[1], y.shape[2]).cpu().numpy()
+    assert y.shape == g[f"{name}_y"].shape
+    np.testing.assert_allclose(y, g[f"{name}_y"], atol=2e-6)          # fp32 round-off of <= 36 taps
+
+
+@pytest.mark.parametrize("shape,mode", [((2, 128, 128, 128), "down"), ((2, 128, 128, 128), "up"),
+                                        ((1, 3, 256, 256), "down"), ((3, 256, 4, 4), "up"), ((1, 5, 37, 53), "down"),
+                                        ((1, 5, 37, 53), "up"), ((1, 2, 70, 130), "same")])
+def test_upfirdn2d_bench_shapes(ops, shape, mode):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(shape).astype(np.float32)
+    k = resample.setup_kernel([1, 3, 3, 1])
+    if mode == "down":
+        args = (1, 1, 2, 2, 1, 1, 1, 1)
+    elif mode == "up":
+        k = k * 4
+        args = (2, 2, 1, 1, 2, 1, 2, 1)
+    else:
+        args = (1, 1, 1, 1, 2, 1, 2, 1)
+    ref = resample.upfirdn2d(x, k, *args)
+    N, C, H, W = shape
+    y = ops.upfirdn2d_raw(dev(x).reshape(N * C, H, W, 1), dev(k), *args)
+    np.testing.assert_allclose(y.reshape(ref.shape).cpu().numpy(), ref, atol=3e-6)
+
+
+def test_upfirdn2d_minor_dim(ops):
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((3, 9, 8, 4)).astype(np.float32)          # [major, h, w, minor]
+    k = rng.standard_normal((3, 3)).astype(np.float32)
+    ref = resample.upfirdn2d(np.transpose(x, (0, 3, 1, 2)), k, 2, 2, 1, 1, 1, 1, 1, 1)
+    y = ops.upfirdn2d_raw(dev(x), dev(k), 2, 2, 1, 1, 1, 1, 1, 1).cpu().numpy()
+    np.testing.assert_allclose(np.transpose(y, (0, 3, 1, 2)), ref, atol=3e-6)
+
+
+def test_fused_bias_act(ops, golden):
+    g = golden("g10_biasact")
+    y = ops.fused_bias_act_raw(dev(g["x"]), dev(g["b"]), None, 3, 0, 0.2, 2 ** 0.5).cpu().numpy()
+    np.testing.assert_allclose(y, g["y_default"], atol=1e-6)
+    y = ops.fused_bias_act_raw(dev(g["x2"]), dev(g["b2"]), None, 3, 0, 0.2, 2 ** 0.5).cpu().numpy()
+    np.testing.assert_allclose(y, g["y2"], atol=1e-6)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 6, 8, 8)).astype(np.float32)
+    b = rng.standard_normal(6).astype(np.float32)
+    ref = rng.standard_normal(x.shape).astype(np.float32)
+    for act, grad in [(1, 0), (1, 1), (1, 2), (3, 0), (3, 1), (3, 2)]:
+        want = resample.bias_act(x, b, ref, act, grad, 0.3, 1.7)
+        got = ops.fused_bias_act_raw(dev(x), dev(b), dev(ref), act, grad, 0.3, 1.7).cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=1e-6, err_msg=f"act={act} grad={grad}")
+    assert ops.fused_bias_act_raw(dev(np.zeros((0, 3), np.float32)), dev(b[:3]), None, 3, 0, 0.2, 1.0).numel() == 0
+
+
+# ---- k-space --------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", ["2x1x8x8", "1x2x7x9", "1x1x32x32", "1x1x6x5"])
+def test_fft2c_golden(ops, golden, shape):
+    g = golden("g03_fft")
+    x = g[f"x_{shape}"]
+    np.testing.assert_allclose(ops.fft2c(dev(x)).cpu().numpy(), g[f"i2k_{shape}"], atol=3e-6)
+    np.testing.assert_allclose(ops.fft2c(dev(x), inverse=True).cpu().numpy(), g[f"k2i_{shape}"], atol=3e-6)
+
+
+@pytest.mark.parametrize("H,W", [(128, 128), (64, 128), (16, 4), (256, 256), (96, 40)])
+def test_fft2c_sizes(ops, H, W):
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal((3, H, W)) + 1j * rng.standard_normal((3, H, W))).astype(np.complex64)
+    k = ops.fft2c(dev(x))
+    ref = kspace.fft2c(x)
+    tol = 2e-5 * np.sqrt(H * W) / 32            # direct DFT path accumulates N terms
+    np.testing.assert_allclose(k.cpu().numpy(), ref, atol=max(tol, 5e-6))
+    np.testing.assert_allclose(ops.fft2c(k, inverse=True).cpu().numpy(), x, atol=max(tol, 5e-6))   # round trip
+    # Parseval (orthonormal transform)
+    assert abs(float((k.abs() ** 2).sum()) / float((np.abs(x) ** 2).sum()) - 1) < 1e-4
+
+
+def _sense_setup(golden):
+    g = golden("g04_sense")
+    maps = kspace.sens_maps(4, 32, 32, 0)
+    return g, maps, dev(maps.astype(np.float32)), dev(g["mask_T1"].reshape(1, 32).astype(np.uint8))
+
+
+def test_sense_ops_golden(ops, golden):
+    g, maps, sens, mask = _sense_setup(golden)
+    y = ops.sense_forward(dev(g["x"]), sens, mask).cpu().numpy()
+    np.testing.assert_allclose(y, g["Ax"], atol=5e-6)
+    np.testing.assert_allclose(ops.sense_adjoint(dev(g["s"]), sens).cpu().numpy(), g["AHs"], atol=5e-6)
+    np.testing.assert_allclose(ops.sense_ssos(dev(g["s"])).cpu().numpy(), g["ssos_s"], atol=5e-6)
+    # the hard-wired T=24 mask of the live reference: image b uses mask row b
+    m24 = dev(g["mask_T24"].reshape(24, 32).astype(np.uint8))
+    np.testing.assert_allclose(ops.sense_forward(dev(g["x24"]), sens, m24).cpu().numpy(), g["Ax24"], atol=5e-6)
+
+
+def test_sense_adjointness_128(ops):
+    rng = np.random.default_rng(5)
+    H = W = 128
+    maps = kspace.sens_maps(4, H, W, 0).astype(np.float32)
+    mask = kspace.generate_mask(1, W, seed=0, **kspace.MASK_PARAMS["R40"]).astype(np.uint8)
+    x = (rng.standard_normal((2, 1, H, W)) + 1j * rng.standard_normal((2, 1, H, W))).astype(np.complex64)
+    s = (rng.standard_normal((4, 2, 1, H, W)) + 1j * rng.standard_normal((4, 2, 1, H, W))).astype(np.complex64)
+    Ax = ops.sense_forward(dev(x), dev(maps), dev(mask)).cpu().numpy().astype(np.complex128)
+    AHs = ops.sense_adjoint(dev(s), dev(maps), dev(mask), apply_mask=True).cpu().numpy().astype(np.complex128)
+    lhs, rhs = np.vdot(s.astype(np.complex128), Ax), np.vdot(AHs, x.astype(np.complex128))
+    assert abs(lhs - rhs) < 1e-4 * abs(lhs)
+    np.testing.assert_allclose(Ax, kspace.sense_forward(x, maps.astype(np.float64), mask[None]), atol=2e-5)
+
+
+def test_l2prox_golden(ops, golden):
+    g, maps, sens, mask = _sense_setup(golden)
+    p = golden("g05_prox")
+    z = p["z"]
+    for i in range(3):
+        alpha, lamda = p[f"l2_sense_{i}_alpha_lamda"]
+        coef = 0.05 * (alpha / lamda) / (4 * 32)
+        o_re, o_im = ops.sense_l2prox(dev(z.real), dev(z.imag), dev(p["y"]), sens, mask, coef)
+        got = o_re.cpu().numpy() + 1j * o_im.cpu().numpy()
+        np.testing.assert_allclose(got, p[f"l2_sense_{i}_x"], atol=3e-6)
+
+
+def test_ald_sense_step_matches_oracle(ops):
+    rng = np.random.default_rng(6)
+    H = W = 128
+    B = 3
+    maps = kspace.sens_maps(4, H, W, 0)
+    mask = kspace.generate_mask(1, W, seed=0, **kspace.MASK_PARAMS["R20"])
+    img = (rng.random((1, 1, H, W)) * np.exp(1j * rng.standard_normal((1, 1, H, W)))).astype(np.complex64)
+    y = np.repeat(kspace.sense_forward(img, maps, mask[None]), B, axis=1)
+    x = (rng.standard_normal((B, 1, H, W)) + 1j * rng.standard_normal((B, 1, H, W))).astype(np.complex64)
+    g = rng.standard_normal((2, B, 1, H, W)).astype(np.float32)
+    n = rng.standard_normal((2, B, 1, H, W)).astype(np.float32)
+    step, ns, alpha = np.float32(0.37), np.float32(np.sqrt(2 * 0.37)), 40.0
+    coef = 0.05 * alpha / (4 * W)
+    z = ((x.real + step * g[0] + n[0] * ns) + 1j * (x.imag + step * g[1] + n[1] * ns)).astype(np.complex64)
+    want = kspace.l2_penalty_sense(z, y, alpha, 1.0, maps, mask[None])
+    x_re, x_im = dev(x.real), dev(x.imag)
+    work = torch.empty(B * H * W * 2, device="cuda")
+    ops.ald_sense_step(x_re, x_im, dev(g[0]), dev(g[1]), dev(y), dev(maps.astype(np.float32)),
+                       dev(mask.astype(np.uint8)), work, step=float(step), noise_scale=float(ns), coef=coef,
+                       noise_re=dev(n[0]), noise_im=dev(n[1]))
+    got = x_re.cpu().numpy() + 1j * x_im.cpu().numpy()
+    assert np.abs(want - z).max() > 1e-3                         # the data term is visible in this test
+    np.testing.assert_allclose(got, want, atol=5e-6)
+    # device-resident schedule struct gives the same result
+    sched = np.zeros(1, dtype=[("step", "f4"), ("ns", "f4"), ("coef", "f4"), ("sigma", "f4"), ("id", "i8")])
+    sched["step"], sched["ns"], sched["coef"] = step, ns, coef
+    x_re2, x_im2 = dev(x.real), dev(x.imag)
+    ops.ald_sense_step(x_re2, x_im2, dev(g[0]), dev(g[1]), dev(y), dev(maps.astype(np.float32)),
+                       dev(mask.astype(np.uint8)), work, noise_re=dev(n[0]), noise_im=dev(n[1]),
+                       dev_sched=dev(sched.view(np.uint8)))
+    assert torch.equal(x_re2, x_re) and torch.equal(x_im2, x_im)
+
+
+def test_langevin_and_philox(ops):
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((5, 1, 33, 31)).astype(np.float32)
+    g = rng.standard_normal(x.shape).astype(np.float32)
+    n = rng.standard_normal(x.shape).astype(np.float32)
+    step, ns = np.float32(0.011), np.float32(np.sqrt(0.022))
+    xd = dev(x)
+    ops.langevin_step(xd, dev(g), float(step), float(ns), noise=dev(n))
+    np.testing.assert_allclose(xd.cpu().numpy(), x + step * g + n * ns, atol=1e-6)
+    # Philox: same numbers regardless of how samples are sharded, standard-normal moments
+    full = ops.philox_normal((8, 128 * 128), "cuda", seed=11, sample_offset=0, step_id=5)
+    part = ops.philox_normal((3, 128 * 128), "cuda", seed=11, sample_offset=4, step_id=5)
+    assert torch.equal(full[4:7], part)
+    assert not torch.equal(full[0], ops.philox_normal((1, 128 * 128), "cuda", seed=11, step_id=6)[0])
+    assert abs(float(full.mean())) < 0.01 and abs(float(full.std()) - 1) < 0.01
+    assert abs(float((full ** 4).mean()) - 3.0) < 0.1
+    xd2 = dev(x.reshape(5, -1))
+    ops.langevin_step(xd2, dev(g.reshape(5, -1)), float(step), float(ns), seed=3, sample_offset=2, step_id=9)
+    nz = ops.philox_normal((5, x[0].size), "cuda", seed=3, sample_offset=2, step_id=9)
+    np.testing.assert_allclose(xd2.cpu().numpy(), (x + step * g).reshape(5, -1) + nz.cpu().numpy() * ns, atol=1e-6)
+
+
+# ---- score-network glue -----------------------------------------------------------------------
+def test_instnorm_plus(ops, golden):
+    g = golden("g07_layers")
+    p = state_dict_from_golden(g, "in")
+    x = dev(g["in_x"])
+    coef = ops.instnorm_plus_coef(x, p["alpha"].cuda(), p["gamma"].cuda(), p["beta"].cuda())
+    y = ops.affine_act(x, coef, ops.ACT_NONE).cpu().numpy()
+    np.testing.assert_allclose(y, g["in_y"], atol=3e-6)
+    y = ops.affine_act(x, coef, ops.ACT_ELU).cpu().numpy()
+    np.testing.assert_allclose(y, F.elu(torch.from_numpy(g["in_y"])).numpy(), atol=3e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 128, 128), (3, 512, 16, 16), (1, 7, 9, 5)])
+def test_instnorm_plus_sizes(ops, shape):
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(shape, generator=gen) * 3 + 50.0            # large mean: exercises the (x - mu) form
+    C = shape[1]
+    p = {"alpha": 1 + 0.1 * torch.randn(C, generator=gen), "gamma": 1 + 0.1 * torch.randn(C, generator=gen),
+         "beta": 0.1 * torch.randn(C, generator=gen)}
+    want = scorenet.instance_norm_plus(x, p)
+    exact = scorenet.instance_norm_plus(x.double(), {k: v.double() for k, v in p.items()})
+    coef = ops.instnorm_plus_coef(x.cuda(), p["alpha"].cuda(), p["gamma"].cuda(), p["beta"].cuda())
+    got = ops.affine_act(x.cuda(), coef, ops.ACT_NONE).cpu()
+    # plane means of 50 +- 0.02 make the cross-channel term ill-conditioned in fp32: judge both the
+    # kernel and the fp32 CPU oracle against float64, the kernel must be at least as accurate
+    err_gpu = (got.double() - exact).abs().max()
+    err_cpu = (want.double() - exact).abs().max()
+    assert err_gpu < max(2e-5, 2 * float(err_cpu)), (float(err_gpu), float(err_cpu))
+
+
+def test_elementwise(ops):
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 5, 17, 13, generator=gen) * 2
+    y = torch.randn(3, 5, 17, 13, generator=gen)
+    for name, fn in [("elu", F.elu), ("relu", F.relu), ("lrelu", lambda t: F.leaky_relu(t, 0.2)),
+                     ("swish", lambda t: t * torch.sigmoid(t))]:
+        got = ops.act(x.cuda(), ops.ACT_CODES[name]).cpu()
+        assert (got - fn(x)).abs().max() < 1e-6, name
+    assert torch.equal(ops.add(x.cuda(), y.cuda()).cpu(), x + y)
+    assert torch.equal(ops.scale_shift(x.cuda(), 2.0, -1.0).cpu(), 2 * x - 1.0)
+    sig = torch.tensor(kspace.get_sigmas(348, 0.01, 2311))
+    labels = torch.tensor([0, 2310, 77])
+    got = ops.div_sigma(x.cuda(), sig.cuda(), labels.cuda()).cpu()
+    assert torch.equal(got, x / sig[labels].view(-1, 1, 1, 1))
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 16), (1, 4, 128, 128), (2, 2, 37, 70), (1, 1, 3, 2)])
+def test_maxpool5(ops, shape):
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(10))
+    assert torch.equal(ops.maxpool5(x.cuda()).cpu(), F.max_pool2d(x, 5, 1, 2))
+
+
+def test_meanpool2(ops):
+    x = torch.randn(2, 5, 12, 10, generator=torch.Generator().manual_seed(11))
+    assert torch.equal(ops.meanpool2(x.cuda()).cpu(), scorenet.mean_pool2(x))
+
+
+@pytest.mark.parametrize("ish,osh", [((6, 5), (12, 10)), ((16, 16), (32, 32)), ((64, 64), (128, 128)),
+                                     ((16, 16), (16, 16)), ((5, 7), (11, 9)), ((1, 1), (4, 4))])
+def test_bilinear(ops, ish, osh):
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 3, *ish, generator=gen)
+    acc = torch.randn(2, 3, *osh, generator=gen)
+    want = F.interpolate(x, size=osh, mode="bilinear", align_corners=True)
+    got = ops.bilinear(x.cuda(), osh).cpu()
+    assert (got - want).abs().max() < 2e-6
+    out = acc.clone().cuda()
+    ops.bilinear(x.cuda(), osh, out=out, accumulate=True)
+    assert (out.cpu() - (acc + want)).abs().max() < 2e-6
+    if ish == osh:
+        assert torch.equal(got, x)                               # identity resize is exact
+
+
+# ---- MFMA convolution ---------------------------------------------------------------------------
+CONV_CASES = [
+    # B, Cin, Cout, H, W, k, dil, fused-norm, act, residual
+    (2, 16, 32, 32, 32, 3, 1, False, "none", False),
+    (2, 128, 128, 64, 64, 3, 1, True, "elu", True),          # big-tile config
+    (1, 128, 256, 32, 32, 3, 1, False, "elu", False),
+    (3, 256, 256, 16, 16, 3, 1, True, "elu", True),          # 16x16 stage
+    (2, 256, 512, 16, 16, 3, 2, True, "elu", False),         # dilation 2
+    (2, 512, 512, 16, 16, 3, 4, False, "elu", True),         # dilation 4
+    (2, 1, 128, 32, 32, 3, 1, False, "none", False),         # begin_conv: Cin = 1
+    (2, 128, 1, 32, 32, 3, 1, True, "elu", False),           # end_conv: Cout = 1
+    (2, 128, 256, 32, 32, 1, 1, False, "none", False),       # 1x1 shortcut
+    (1, 6, 5, 12, 10, 3, 1, True, "elu", True),              # ragged everything
+    (1, 7, 9, 19, 45, 3, 1, False, "relu", False),
+    (2, 24, 40, 8, 8, 3, 2, False, "none", False),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,dil,norm,actname,res", CONV_CASES)
+def test_conv2d(ops, B, Cin, Cout, H, W, k, dil, norm, actname, res):
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=gen)
+    resid = torch.randn(B, Cout, H, W, generator=gen) if res else None
+    p = {"alpha": 1 + 0.1 * torch.randn(Cin, generator=gen), "gamma": 1 + 0.1 * torch.randn(Cin, generator=gen),
+         "beta": 0.1 * torch.randn(Cin, generator=gen)}
+    fn = {"none": lambda t: t, "elu": F.elu, "relu": F.relu}[actname]
+    h = scorenet.instance_norm_plus(x.double(), {a: b.double() for a, b in p.items()}) if norm else x.double()
+    want = F.conv2d(fn(h), w.double(), bias.double(), padding=(k // 2) * dil, dilation=dil)
+    if res:
+        want = want + resid.double()
+    xd = x.cuda()
+    coef = ops.instnorm_plus_coef(xd, p["alpha"].cuda(), p["gamma"].cuda(), p["beta"].cuda()) if norm else None
+    wt = ops.conv_pack_weight(w.cuda())
+    assert torch.equal(wt.cpu(), w.permute(2, 3, 1, 0).reshape(k * k, Cin, Cout))
+    got = ops.conv2d(xd, wt, bias.cuda(), coef, ops.ACT_CODES[actname], None if resid is None else resid.cuda(), dil)
+    # fp32 fma chain over K = Cin*k*k products of O(1) terms normalised to unit variance
+    err = (got.cpu().double() - want).abs().max()
+    assert err < 2e-5 * max(1.0, float(want.abs().max())), float(err)
+
+
+def test_conv2d_mfma_layout_identity(ops):
+    """A = identity-like weights with an asymmetric input catches a transposed accumulator map."""
+    Cin = Cout = 64
+    x = torch.arange(2 * Cin * 8 * 32, dtype=torch.float32).reshape(2, Cin, 8, 32) % 251
+    w = torch.zeros(Cout, Cin, 3, 3)
+    for c in range(Cout):
+        w[c, (c * 7 + 3) % Cin, 1, 1] = 1.0          # a permutation of channels, centre tap only
+    got = ops.conv2d(x.cuda(), ops.conv_pack_weight(w.cuda())).cpu()
+    want = x[:, [(c * 7 + 3) % Cin for c in range(Cout)]]
+    assert torch.equal(got, want)
