@@ -274,7 +274,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t s) {
     if (a.Cout >= 512 && px >= 4096) return launch_conv<1, 2, 2, 2, 16, 4, 8, KS>(a, s);   // 64 co x 128 px
     return launch_conv<1, 1, 1, 4, 16, 4, 8, KS>(a, s);                                    // 32 co x 128 px
   }
-  if (a.dil > 1) return IPDM_EUNSUPPORTED;
+  if (a.dil > 1) return launch_conv<1, 4, 2, 2, 32, 4, 8, KS>(a, s);                       // dilated, wide images
   if (a.Cout <= 32) return launch_conv<1, 2, 1, 4, 32, 1, 8, KS>(a, s);                    // 32 co x 256 px
   if (a.Cout <= 64 || px < 65536) return launch_conv<1, 4, 2, 2, 32, 1, 8, KS>(a, s);      // 64 co x 256 px
   return launch_conv<4, 2, 1, 4, 32, 1, 8, KS>(a, s);                                      // 128 co x 256 px

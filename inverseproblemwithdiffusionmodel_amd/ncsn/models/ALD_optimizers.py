@@ -1,0 +1,242 @@
+"""Annealed Langevin Dynamics samplers (mirror of the reference's ``ncsn/models/ALD_optimizers.py``:
+get_lh_weights :23-38, ALDOptimizer :49-155, ALDUnconditionalSampler :158, ALDInvSegProximalRealImag
+:161-327).  Same constructors, ``params`` keys (n_steps_each, step_lr, denoise, final_only), call kwargs
+and return value (a list holding the final CPU tensor).
+
+What runs where: the schedule arithmetic (step sizes) is float32 host math identical to the reference;
+everything per pixel runs in libipdm.so.  For the SENSE sampler one iteration is
+    score network on the (2B, 1, H, W) batch [real planes | imaginary planes]   (InstanceNorm is per image,
+                                               so batching the two reference passes is exact)
+    one fused kernel: Langevin update of both planes + L2Penalty proximal (FFT in LDS)
+and, with ``use_graph=True`` (default), the whole iteration is captured once into a hipGraph and replayed
+for all L * n_steps_each steps; per-step scalars live in a device-side ipdm_sched_t.
+
+Extra, optional call kwargs (none changes the defaults' semantics):
+    noise_fn(like) -> tensor   injected Langevin noise (parity runs; the reference draws torch.randn_like
+                               on the compute device, which is not reproducible across devices)
+    seed, sample_offset        Philox key / first global sample id of this shard (default noise source)
+    verbose                    per-level progress prints (the reference's per-step prints are host syncs)
+    use_graph                  capture/replay one iteration as a hipGraph
+Differences kept on purpose: the reference's per-step ``print(max, min)`` syncs and PNG dumps are gone;
+``torch.set_grad_enabled(False)`` is scoped to the call instead of leaking globally.
+Segmentation guidance (``adjust_grad`` -> compute_seg_grad) is a "next" row: a ``seg`` net
+is honoured only where its weight is zero (``seg_start_time == 1``), anything else raises.
+"""
+import abc
+
+import numpy as np
+import torch
+
+from ... import ops
+from .proximal_op import Proximal, L2Penalty, Constrained, SingleCoil  # noqa: F401
+from ..linear_transforms.undersampling_fourier import SENSE
+from ...helpers.utils import data_transform
+
+SCHED_DTYPE = np.dtype([("step", "<f4"), ("noise_scale", "<f4"), ("coef", "<f4"), ("sigma", "<f4"),
+                        ("step_id", "<i8")])
+
+
+def get_lh_weights(sigmas, start_time, curve_type="linear"):
+    assert 0 <= start_time <= 1
+    lh_weights = torch.zeros_like(sigmas)
+    if start_time == 1:
+        return lh_weights
+    start_idx = int(len(sigmas) * start_time)
+    if curve_type == "linear":
+        lh_weights[start_idx:] = torch.linspace(0, 1, len(sigmas) - start_idx, device=sigmas.device)
+        return lh_weights
+    raise NotImplementedError
+
+
+def step_schedule(sigmas, step_lr):
+    """float32 host tensors (step_size[c], sqrt(2 step_size[c])) computed exactly as the reference's
+    ``step_lr * (sigma / sigmas[-1]) ** 2`` and ``torch.sqrt(step_size * 2)`` (:217, :239)."""
+    s = sigmas.detach().to("cpu", torch.float32)
+    step = step_lr * (s / s[-1]) ** 2
+    return step, torch.sqrt(step * 2)
+
+
+class ALDOptimizer(abc.ABC):
+    def __init__(self, x_mod_shape, scorenet, sigmas, params, config,
+                 measurement=None, linear_tfm=None, clf=None, seg=None, device=None):
+        """params: n_steps_each, step_lr, denoise, final_only"""
+        self.x_mod_shape = x_mod_shape
+        self.scorenet = scorenet
+        self.sigmas = sigmas
+        self.params = params
+        self.config = config
+        self.measurement = measurement
+        self.linear_tfm = linear_tfm
+        self.clf = clf
+        self.seg = seg
+        self.device = device if device is not None else torch.device("cuda")
+
+    @torch.no_grad()
+    def __call__(self, **kwargs):
+        scorenet, sigmas = self.scorenet, self.sigmas
+        n_steps_each, step_lr = self.params["n_steps_each"], self.params["step_lr"]
+        denoise, final_only = self.params["denoise"], self.params["final_only"]
+        noise_fn = kwargs.get("noise_fn")
+        seed, sample_offset = kwargs.get("seed", 0), kwargs.get("sample_offset", 0)
+        verbose = kwargs.get("verbose", False)
+
+        x_mod = self.init_x_mod()
+        x_mod = data_transform(self.config, x_mod).contiguous()
+        images = []
+        self.preprocessing_steps(**kwargs)
+        steps, noise_scales = step_schedule(sigmas, step_lr)
+        B = x_mod.shape[0]
+        it = 0
+        for c in range(len(sigmas)):
+            if verbose and c % max(len(sigmas) // 10, 1) == 0:
+                print(f"{c + 1}/{len(sigmas)}")
+            labels = torch.full((B,), c, dtype=torch.long, device=x_mod.device)
+            x_mod = self.init_estimation(x_mod, alpha=steps[c], **kwargs)
+            for s in range(n_steps_each):
+                grad = scorenet(x_mod, labels)
+                grad = self.adjust_grad(grad, x_mod, sigma=sigmas[c], **kwargs)
+                noise = None if noise_fn is None else noise_fn(x_mod).to(x_mod.device)
+                ops.langevin_step(x_mod, grad, float(steps[c]), float(noise_scales[c]), noise=noise, seed=seed,
+                                  sample_offset=sample_offset, step_id=it)
+                it += 1
+                if not final_only:
+                    images.append(x_mod.to('cpu'))
+        if denoise:
+            last = torch.full((B,), len(sigmas) - 1, dtype=torch.long, device=x_mod.device)
+            s2 = float(sigmas.detach().cpu()[-1] ** 2)
+            ops.langevin_step(x_mod, scorenet(x_mod, last), s2, 0.0, noise=torch.zeros_like(x_mod))
+            images.append(x_mod.to('cpu'))
+        if final_only:
+            return [x_mod.to('cpu')]
+        return images
+
+    def preprocessing_steps(self, **kwargs):
+        pass
+
+    def init_x_mod(self):
+        return torch.rand(*self.x_mod_shape).to(self.device)     # CPU generator, as the reference (:145)
+
+    def init_estimation(self, x_mod, **kwargs):
+        return x_mod
+
+    def adjust_grad(self, grad, x_mod, **kwargs):
+        return grad
+
+
+class ALDUnconditionalSampler(ALDOptimizer):
+    pass
+
+
+class ALDInvSegProximalRealImag(ALDOptimizer):
+    def __init__(self, proximal: Proximal, seg_start_time, seg_step_type, *args, **kwargs):
+        super(ALDInvSegProximalRealImag, self).__init__(*args, **kwargs)
+        self.proximal = proximal
+        self.seg_start_time = seg_start_time
+        self.seg_step_type = seg_step_type
+        self.lh_weights = get_lh_weights(self.sigmas, self.seg_start_time, self.seg_step_type)
+        self.if_print = False
+        self.print_args = {}
+        self._graph = None
+
+    # -- one iteration = score net on [real | imag] + fused Langevin/proximal tail ------------------
+    def _iteration(self, st):
+        grad = self.scorenet(st["x"], st["labels"])
+        B = st["B"]
+        ops.ald_sense_step(st["x"][:B], st["x"][B:], grad[:B], grad[B:], st["y"], st["sens"], st["mask"], st["work"],
+                           noise_re=st["noise_re"], noise_im=st["noise_im"], seed=st["seed"],
+                           sample_offset=st["sample_offset"], dev_sched=st["sched_dev"])
+
+    def _check_fast_path(self, kwargs):
+        if not isinstance(self.proximal, L2Penalty) or not isinstance(self.linear_tfm, SENSE):
+            raise NotImplementedError("the fused iteration covers L2Penalty + SENSE (the shipped ACDC/CINE setting); "
+                                      f"got {type(self.proximal).__name__} + {type(self.linear_tfm).__name__}")
+        if self.seg is not None and bool((self.lh_weights != 0).any()):
+            raise NotImplementedError("segmentation-likelihood guidance with non-zero weight is not built yet "
+                                      "(SURVEY.md 8f rank 1); use seg_start_time=1 or seg=None")
+
+    @torch.no_grad()
+    def __call__(self, **kwargs):
+        """kwargs: label, lamda, save_dir, lr_scaled, seg_mode (+ noise_fn, seed, sample_offset, verbose, use_graph,
+        n_levels/start_level to run a slice of the schedule)"""
+        self._check_fast_path(kwargs)
+        sigmas = self.sigmas
+        n_steps_each, step_lr = self.params["n_steps_each"], self.params["step_lr"]
+        denoise = self.params["denoise"]
+        lr_scaled = kwargs.get("lr_scaled", 1.)
+        noise_fn = kwargs.get("noise_fn")
+        verbose = kwargs.get("verbose", False)
+        use_graph = kwargs.get("use_graph", True)
+        dev = self.device
+        meas = self.measurement.to(dev).to(torch.complex64).contiguous()
+        lin = self.linear_tfm
+
+        x0 = kwargs.get("x_init")
+        x0 = lin.conj_op(meas) if x0 is None else x0.to(dev)                  # zero-filled SENSE recon
+        B, H, W = x0.shape[0], x0.shape[-2], x0.shape[-1]
+        x = torch.cat([x0.real, x0.imag], dim=0).contiguous().float()        # (2B, 1, H, W)
+        steps, noise_scales = step_schedule(sigmas, step_lr)
+        coef = self.proximal.coef(step_lr * lr_scaled, 1., x0.shape)           # alpha = UNscaled lr (:247,313)
+        L = len(sigmas)
+        lv0 = kwargs.get("start_level", 0)
+        lv1 = L if kwargs.get("n_levels") is None else min(L, lv0 + kwargs["n_levels"])
+
+        st = dict(x=x, B=B, y=meas, sens=lin.sens_f32(dev), mask=lin.mask_u8(dev),
+                  work=torch.empty(B * H * W * 2, dtype=torch.float32, device=dev),
+                  labels=torch.zeros(2 * B, dtype=torch.long, device=dev),
+                  noise_re=None, noise_im=None, seed=kwargs.get("seed", 0),
+                  sample_offset=kwargs.get("sample_offset", 0),
+                  sched_dev=torch.zeros(SCHED_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+        if noise_fn is not None:
+            st["noise_re"] = torch.empty(B, 1, H, W, device=dev)
+            st["noise_im"] = torch.empty(B, 1, H, W, device=dev)
+        # all per-step scalars for the run, uploaded once; each step copies its 24-byte record on-stream
+        n_it = (lv1 - lv0) * n_steps_each
+        table = np.zeros(n_it, dtype=SCHED_DTYPE)
+        lv = np.repeat(np.arange(lv0, lv1), n_steps_each)
+        table["step"], table["noise_scale"] = steps.numpy()[lv], noise_scales.numpy()[lv]
+        table["coef"], table["sigma"] = coef, sigmas.detach().cpu().numpy()[lv]
+        table["step_id"] = lv0 * n_steps_each + np.arange(n_it)
+        table_dev = torch.from_numpy(table.view(np.uint8).reshape(n_it, -1).copy()).to(dev)
+        label_table = torch.from_numpy(np.repeat(lv[:, None], 2 * B, axis=1)).to(dev)
+
+        graph = None
+        for k in range(n_it):
+            c = int(lv[k])
+            if verbose and k % n_steps_each == 0 and c % max(L // 10, 1) == 0:
+                print(f"{c + 1}/{L}")
+            st["sched_dev"].copy_(table_dev[k], non_blocking=True)
+            st["labels"].copy_(label_table[k], non_blocking=True)
+            if noise_fn is not None:
+                st["noise_re"].copy_(noise_fn(x[:B]).to(dev))
+                st["noise_im"].copy_(noise_fn(x[B:]).to(dev))
+            if not use_graph:
+                self._iteration(st)
+            elif graph is None:
+                self._iteration(st)                      # warm-up (weight packing, LDS attributes, allocator)
+                if k + 1 < n_it:
+                    graph = self._capture(st)
+            else:
+                graph.replay()
+        if denoise and lv1 == L:
+            st["labels"].fill_(L - 1)
+            s2 = float(sigmas.detach().cpu()[-1] ** 2)
+            ops.langevin_step(x, self.scorenet(x, st["labels"]), s2, 0.0, noise=torch.zeros_like(x))
+        out = torch.complex(x[:B], x[B:])
+        self._last_state = st
+        return [out.to('cpu')]
+
+    def _capture(self, st):
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._iteration(st)
+        return g
+
+    def adjust_grad(self, grad, m_mod, **kwargs):
+        return grad
+
+    def post_processing(self, x_mod_real, x_mod_imag, **kwargs):
+        """reference hook (:288-327): proximal(x, measurement, alpha * lr_scaled, 1.) on separate planes"""
+        x = torch.complex(x_mod_real, x_mod_imag)
+        x = self.proximal(x, self.measurement.to(x.device), kwargs["alpha"] * kwargs["lr_scaled"], 1.)
+        return torch.real(x).contiguous(), torch.imag(x).contiguous()

@@ -1,0 +1,236 @@
+"""RefineNet-style building blocks of the NCSNv2 family (mirror of the reference's
+``ncsn/models/layers.py``: get_act :11-23, conv1x1/conv3x3/dilated_conv3x3 :28-60, CRPBlock :62-83,
+RCUBlock :112-134, MSFBlock :165-184, RefineBlock :214-249, ConvMeanPool :291-313, ResidualBlock :401-456).
+
+Same parameter names / state-dict keys as the reference, different execution: every block is a short
+chain of libipdm.so launches.  Normalisation + activation are folded into the next convolution's input
+staging, bias / residual adds into its epilogue; the 5x5 max-pool, 2x2 mean-pool and bilinear
+accumulate are single kernels."""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .normalization import InstanceNorm2dPlus, get_normalization  # noqa: F401
+
+
+class _Act:
+    """activation handle: carries the kernel code; callable on tensors like the reference's nn.ELU()"""
+
+    def __init__(self, name):
+        self.name = name
+        self.code = ops.ACT_CODES[name]
+
+    def __call__(self, x):
+        return ops.act(x, self.code)
+
+
+def get_act(config):
+    name = config.model.nonlinearity.lower()
+    if name not in ("elu", "relu", "lrelu", "swish"):
+        raise NotImplementedError("activation function does not exist!")
+    return _Act(name)
+
+
+def _act_code(act):
+    if act is None:
+        return ops.ACT_NONE
+    if isinstance(act, _Act):
+        return act.code
+    if isinstance(act, nn.ELU):
+        return ops.ACT_ELU
+    if isinstance(act, nn.ReLU):
+        return ops.ACT_RELU
+    raise NotImplementedError(f"no kernel code for activation {act!r}")
+
+
+class Conv2d(nn.Module):
+    """stride-1 'same' convolution, kernel 1 or 3, optional dilation; weight in the reference's layout
+    [Cout, Cin, k, k] (what checkpoints carry), repacked once to [k*k, Cin, Cout] for the MFMA kernel."""
+
+    def __init__(self, in_planes, out_planes, kernel_size=3, dilation=1, bias=True):
+        super().__init__()
+        assert kernel_size in (1, 3)
+        self.in_planes, self.out_planes, self.kernel_size, self.dilation = in_planes, out_planes, kernel_size, dilation
+        self.weight = nn.Parameter(torch.empty(out_planes, in_planes, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_planes)) if bias else None
+        bound = 1.0 / (in_planes * kernel_size * kernel_size) ** 0.5
+        nn.init.uniform_(self.weight, -bound, bound)
+        if bias:
+            nn.init.uniform_(self.bias, -bound, bound)
+        self._packed = None
+        self._packed_version = None
+
+    def packed(self):
+        v = (self.weight._version, self.weight.data_ptr())
+        if self._packed is None or self._packed_version != v:
+            self._packed = ops.conv_pack_weight(self.weight.data)
+            self._packed_version = v
+        return self._packed
+
+    def forward(self, x, coef=None, act=ops.ACT_NONE, residual=None, out=None):
+        return ops.conv2d(x, self.packed(), None if self.bias is None else self.bias.data, coef, act, residual,
+                          self.dilation, out=out)
+
+
+def conv1x1(in_planes, out_planes, stride=1, bias=True, spec_norm=False):
+    assert stride == 1 and not spec_norm
+    return Conv2d(in_planes, out_planes, 1, bias=bias)
+
+
+def conv3x3(in_planes, out_planes, stride=1, bias=True, spec_norm=False):
+    assert stride == 1 and not spec_norm
+    return Conv2d(in_planes, out_planes, 3, bias=bias)
+
+
+def dilated_conv3x3(in_planes, out_planes, dilation, bias=True, spec_norm=False):
+    assert not spec_norm
+    return Conv2d(in_planes, out_planes, 3, dilation=dilation, bias=bias)
+
+
+class ConvMeanPool(nn.Module):
+    def __init__(self, input_dim, output_dim, kernel_size=3, biases=True, adjust_padding=False, spec_norm=False):
+        super().__init__()
+        if adjust_padding or spec_norm:
+            raise NotImplementedError("adjust_padding / spec_norm are unused by every shipped config")
+        self.conv = Conv2d(input_dim, output_dim, kernel_size, bias=biases)
+
+    def forward(self, inputs, coef=None, act=ops.ACT_NONE):
+        return ops.meanpool2(self.conv(inputs, coef, act))
+
+
+class CRPBlock(nn.Module):
+    def __init__(self, features, n_stages, act=None, maxpool=True, spec_norm=False):
+        super().__init__()
+        if not maxpool:
+            raise NotImplementedError("average-pool CRP is unused by every shipped config")
+        self.convs = nn.ModuleList([conv3x3(features, features, bias=False, spec_norm=spec_norm)
+                                    for _ in range(n_stages)])
+        self.n_stages = n_stages
+        self.act = act
+
+    def forward(self, x):
+        x = ops.act(x, _act_code(self.act))
+        path = x
+        for i in range(self.n_stages):
+            pooled = ops.maxpool5(path)
+            if i == self.n_stages - 1:
+                x = self.convs[i](pooled, residual=x)          # x = conv(pool(path)) + x in one launch
+            else:
+                path = self.convs[i](pooled)
+                x = ops.add(path, x)
+        return x
+
+
+class RCUBlock(nn.Module):
+    def __init__(self, features, n_blocks, n_stages, act=None, spec_norm=False):
+        super().__init__()
+        for i in range(n_blocks):
+            for j in range(n_stages):
+                setattr(self, '{}_{}_conv'.format(i + 1, j + 1), conv3x3(features, features, bias=False,
+                                                                         spec_norm=spec_norm))
+        self.stride = 1
+        self.n_blocks = n_blocks
+        self.n_stages = n_stages
+        self.act = act
+
+    def forward(self, x):
+        code = _act_code(self.act)
+        for i in range(self.n_blocks):
+            residual = x
+            for j in range(self.n_stages):
+                conv = getattr(self, '{}_{}_conv'.format(i + 1, j + 1))
+                x = conv(x, act=code, residual=residual if j == self.n_stages - 1 else None)
+        return x
+
+
+class MSFBlock(nn.Module):
+    def __init__(self, in_planes, features, spec_norm=False):
+        super().__init__()
+        assert isinstance(in_planes, (list, tuple))
+        self.convs = nn.ModuleList([conv3x3(p, features, bias=True, spec_norm=spec_norm) for p in in_planes])
+        self.features = features
+
+    def forward(self, xs, shape):
+        shape = tuple(int(s) for s in shape)
+        sums = None
+        for i, conv in enumerate(self.convs):
+            same = tuple(xs[i].shape[2:]) == shape
+            if same:
+                sums = conv(xs[i], residual=sums)              # bilinear resize to the same size is exact
+            else:
+                h = conv(xs[i])
+                sums = ops.bilinear(h, shape, out=sums, accumulate=sums is not None)
+        return sums
+
+
+class RefineBlock(nn.Module):
+    def __init__(self, in_planes, features, act=None, start=False, end=False, maxpool=True, spec_norm=False):
+        super().__init__()
+        assert isinstance(in_planes, (tuple, list))
+        self.n_blocks = n_blocks = len(in_planes)
+        self.adapt_convs = nn.ModuleList([RCUBlock(in_planes[i], 2, 2, act, spec_norm=spec_norm)
+                                          for i in range(n_blocks)])
+        self.output_convs = RCUBlock(features, 3 if end else 1, 2, act, spec_norm=spec_norm)
+        if not start:
+            self.msf = MSFBlock(in_planes, features, spec_norm=spec_norm)
+        self.crp = CRPBlock(features, 2, act, maxpool=maxpool, spec_norm=spec_norm)
+
+    def forward(self, xs, output_shape):
+        assert isinstance(xs, (tuple, list))
+        hs = [self.adapt_convs[i](xs[i]) for i in range(len(xs))]
+        h = self.msf(hs, output_shape) if self.n_blocks > 1 else hs[0]
+        h = self.crp(h)
+        return self.output_convs(h)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, input_dim, output_dim, resample=None, act=None, normalization=InstanceNorm2dPlus,
+                 adjust_padding=False, dilation=None, spec_norm=False):
+        super().__init__()
+        self.non_linearity = act
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.resample = resample
+        self.normalization = normalization
+        if resample == 'down':
+            if dilation is not None:
+                self.conv1 = dilated_conv3x3(input_dim, input_dim, dilation=dilation, spec_norm=spec_norm)
+                self.normalize2 = normalization(input_dim)
+                self.conv2 = dilated_conv3x3(input_dim, output_dim, dilation=dilation, spec_norm=spec_norm)
+                conv_shortcut = partial(dilated_conv3x3, dilation=dilation, spec_norm=spec_norm)
+            else:
+                self.conv1 = conv3x3(input_dim, input_dim, spec_norm=spec_norm)
+                self.normalize2 = normalization(input_dim)
+                self.conv2 = ConvMeanPool(input_dim, output_dim, 3, adjust_padding=adjust_padding, spec_norm=spec_norm)
+                conv_shortcut = partial(ConvMeanPool, kernel_size=1, adjust_padding=adjust_padding,
+                                        spec_norm=spec_norm)
+        elif resample is None:
+            if dilation is not None:
+                conv_shortcut = partial(dilated_conv3x3, dilation=dilation, spec_norm=spec_norm)
+                self.conv1 = dilated_conv3x3(input_dim, output_dim, dilation=dilation, spec_norm=spec_norm)
+                self.normalize2 = normalization(output_dim)
+                self.conv2 = dilated_conv3x3(output_dim, output_dim, dilation=dilation, spec_norm=spec_norm)
+            else:
+                conv_shortcut = partial(conv1x1, spec_norm=spec_norm)
+                self.conv1 = conv3x3(input_dim, output_dim, spec_norm=spec_norm)
+                self.normalize2 = normalization(output_dim)
+                self.conv2 = conv3x3(output_dim, output_dim, spec_norm=spec_norm)
+        else:
+            raise Exception('invalid resample value')
+        if output_dim != input_dim or resample is not None:
+            self.shortcut = conv_shortcut(input_dim, output_dim)
+        self.normalize1 = normalization(input_dim)
+
+    def forward(self, x):
+        code = _act_code(self.non_linearity)
+        h = self.conv1(x, self.normalize1.coef(x), code)
+        coef2 = self.normalize2.coef(h)
+        if self.output_dim == self.input_dim and self.resample is None:
+            shortcut = x
+        else:
+            shortcut = self.shortcut(x)
+        if isinstance(self.conv2, ConvMeanPool):
+            return ops.add(shortcut, self.conv2(h, coef2, code))
+        return self.conv2(h, coef2, code, residual=shortcut)

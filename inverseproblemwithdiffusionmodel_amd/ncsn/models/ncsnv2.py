@@ -1,0 +1,152 @@
+"""NCSNv2 score networks (mirror of the reference's ``ncsn/models/ncsnv2.py``: NCSNv2 :11-101,
+NCSNv2Deeper :104-195, NCSNv2Deepest :198-299).  ``scorenet(x (B,C,H,W) f32, labels (B,) int64)`` on GPU
+tensors; same constructor (``Ctor(config)``), ``.sigmas`` buffer, ``.config`` and state-dict keys."""
+import torch
+import torch.nn as nn
+
+from . import get_sigmas
+from .layers import ResidualBlock, RefineBlock, Conv2d, get_act, get_normalization
+from ... import ops
+
+
+class _NCSNv2Base(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.logit_transform = config.data.logit_transform
+        self.rescaled = config.data.rescaled
+        self.norm = get_normalization(config, conditional=False)
+        self.ngf = config.model.ngf
+        self.num_classes = config.model.num_classes
+        self.act = get_act(config)
+        self.register_buffer('sigmas', get_sigmas(config))
+        self.config = config
+        self._in_coef = {}
+
+    def _compute_cond_module(self, module, x):
+        for m in module:
+            x = m(x)
+        return x
+
+    def _stage(self, cin, cout, resample=None, dilation=None):
+        kw = dict(act=self.act, normalization=self.norm)
+        if dilation is not None:
+            kw["dilation"] = dilation
+        return nn.ModuleList([ResidualBlock(cin, cout, resample=resample, **kw),
+                              ResidualBlock(cout, cout, resample=None, **kw)])
+
+    def _begin(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("score network: expected GPU tensors (no CPU fallback in this build)")
+        x = x.contiguous().float()
+        if not self.logit_transform and not self.rescaled:
+            # h = 2x - 1 folded into begin_conv's input staging as (x - 0.5) * 2 + 0
+            key = (x.shape[0], x.shape[1], str(x.device))
+            if key not in self._in_coef:
+                self._in_coef[key] = torch.tensor([0.5, 2.0, 0.0], device=x.device).repeat(x.shape[0], x.shape[1], 1)
+            return self.begin_conv(x, self._in_coef[key])
+        return self.begin_conv(x)
+
+    def _end(self, output, x, y):
+        output = self.end_conv(output, self.normalizer.coef(output), self.act.code)
+        return ops.div_sigma(output, self.sigmas, y.to(torch.int64))
+
+
+class NCSNv2Deepest(_NCSNv2Base):
+    def __init__(self, config):
+        super().__init__(config)
+        ngf, ch = self.ngf, config.data.channels
+        self.begin_conv = Conv2d(ch, ngf, 3)
+        self.normalizer = self.norm(ngf)
+        self.end_conv = Conv2d(ngf, ch, 3)
+        self.res1 = self._stage(ngf, ngf)
+        self.res2 = self._stage(ngf, 2 * ngf, 'down')
+        self.res3 = self._stage(2 * ngf, 2 * ngf, 'down')
+        self.res31 = self._stage(2 * ngf, 2 * ngf, 'down')
+        self.res4 = self._stage(2 * ngf, 4 * ngf, 'down', dilation=2)
+        self.res5 = self._stage(4 * ngf, 4 * ngf, 'down', dilation=4)
+        self.refine1 = RefineBlock([4 * ngf], 4 * ngf, act=self.act, start=True)
+        self.refine2 = RefineBlock([4 * ngf, 4 * ngf], 2 * ngf, act=self.act)
+        self.refine3 = RefineBlock([2 * ngf, 2 * ngf], 2 * ngf, act=self.act)
+        self.refine31 = RefineBlock([2 * ngf, 2 * ngf], 2 * ngf, act=self.act)
+        self.refine4 = RefineBlock([2 * ngf, 2 * ngf], ngf, act=self.act)
+        self.refine5 = RefineBlock([ngf, ngf], ngf, act=self.act, end=True)
+
+    def forward(self, x, y):
+        output = self._begin(x)
+        layer1 = self._compute_cond_module(self.res1, output)
+        layer2 = self._compute_cond_module(self.res2, layer1)
+        layer3 = self._compute_cond_module(self.res3, layer2)
+        layer31 = self._compute_cond_module(self.res31, layer3)
+        layer4 = self._compute_cond_module(self.res4, layer31)
+        layer5 = self._compute_cond_module(self.res5, layer4)
+        ref1 = self.refine1([layer5], layer5.shape[2:])
+        ref2 = self.refine2([layer4, ref1], layer4.shape[2:])
+        ref31 = self.refine31([layer31, ref2], layer31.shape[2:])
+        ref3 = self.refine3([layer3, ref31], layer3.shape[2:])
+        ref4 = self.refine4([layer2, ref3], layer2.shape[2:])
+        output = self.refine5([layer1, ref4], layer1.shape[2:])
+        return self._end(output, x, y)
+
+
+class NCSNv2Deeper(_NCSNv2Base):
+    def __init__(self, config):
+        super().__init__(config)
+        ngf, ch = self.ngf, config.data.channels
+        self.begin_conv = Conv2d(ch, ngf, 3)
+        self.normalizer = self.norm(ngf)
+        self.end_conv = Conv2d(ngf, ch, 3)
+        self.res1 = self._stage(ngf, ngf)
+        self.res2 = self._stage(ngf, 2 * ngf, 'down')
+        self.res3 = self._stage(2 * ngf, 2 * ngf, 'down')
+        self.res4 = self._stage(2 * ngf, 4 * ngf, 'down', dilation=2)
+        self.res5 = self._stage(4 * ngf, 4 * ngf, 'down', dilation=4)
+        self.refine1 = RefineBlock([4 * ngf], 4 * ngf, act=self.act, start=True)
+        self.refine2 = RefineBlock([4 * ngf, 4 * ngf], 2 * ngf, act=self.act)
+        self.refine3 = RefineBlock([2 * ngf, 2 * ngf], 2 * ngf, act=self.act)
+        self.refine4 = RefineBlock([2 * ngf, 2 * ngf], ngf, act=self.act)
+        self.refine5 = RefineBlock([ngf, ngf], ngf, act=self.act, end=True)
+
+    def forward(self, x, y):
+        output = self._begin(x)
+        layer1 = self._compute_cond_module(self.res1, output)
+        layer2 = self._compute_cond_module(self.res2, layer1)
+        layer3 = self._compute_cond_module(self.res3, layer2)
+        layer4 = self._compute_cond_module(self.res4, layer3)
+        layer5 = self._compute_cond_module(self.res5, layer4)
+        ref1 = self.refine1([layer5], layer5.shape[2:])
+        ref2 = self.refine2([layer4, ref1], layer4.shape[2:])
+        ref3 = self.refine3([layer3, ref2], layer3.shape[2:])
+        ref4 = self.refine4([layer2, ref3], layer2.shape[2:])
+        output = self.refine5([layer1, ref4], layer1.shape[2:])
+        return self._end(output, x, y)
+
+
+class NCSNv2(_NCSNv2Base):
+    def __init__(self, config):
+        super().__init__(config)
+        ngf, ch = self.ngf, config.data.channels
+        self.begin_conv = Conv2d(ch, ngf, 3)
+        self.normalizer = self.norm(ngf)
+        self.end_conv = Conv2d(ngf, ch, 3)
+        self.res1 = self._stage(ngf, ngf)
+        self.res2 = self._stage(ngf, 2 * ngf, 'down')
+        self.res3 = self._stage(2 * ngf, 2 * ngf, 'down', dilation=2)
+        if config.data.image_size == 28:
+            raise NotImplementedError("the 28-pixel adjust_padding branch (ncsnv2.py:50-56) is unused by shipped configs")
+        self.res4 = self._stage(2 * ngf, 2 * ngf, 'down', dilation=4)
+        self.refine1 = RefineBlock([2 * ngf], 2 * ngf, act=self.act, start=True)
+        self.refine2 = RefineBlock([2 * ngf, 2 * ngf], 2 * ngf, act=self.act)
+        self.refine3 = RefineBlock([2 * ngf, 2 * ngf], ngf, act=self.act)
+        self.refine4 = RefineBlock([ngf, ngf], ngf, act=self.act, end=True)
+
+    def forward(self, x, y):
+        output = self._begin(x)
+        layer1 = self._compute_cond_module(self.res1, output)
+        layer2 = self._compute_cond_module(self.res2, layer1)
+        layer3 = self._compute_cond_module(self.res3, layer2)
+        layer4 = self._compute_cond_module(self.res4, layer3)
+        ref1 = self.refine1([layer4], layer4.shape[2:])
+        ref2 = self.refine2([layer3, ref1], layer3.shape[2:])
+        ref3 = self.refine3([layer2, ref2], layer2.shape[2:])
+        output = self.refine4([layer1, ref3], layer1.shape[2:])
+        return self._end(output, x, y)

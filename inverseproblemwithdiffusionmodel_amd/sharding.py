@@ -1,0 +1,45 @@
+"""Posterior-sample sharding over the GPUs of one node (new functionality: the reference is
+single-process, SURVEY.md 2 'Parallelism').  Samples are independent given (measurement, mask, coils,
+weights), so the data path has NO collective: global sample ids are block-partitioned over ranks, each
+sample's Langevin noise is keyed by its global id (results do not depend on the number of GPUs), and
+the only exchange is one all-reduce(SUM) of six moment planes at the end (RCCL over xGMI on GPUs, gloo in
+the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_sizes(total, world_size):
+    """block partition, remainder to the lowest ranks: 105 over 8 -> [14, 13, 13, 13, 13, 13, 13, 13]"""
+    base, rem = divmod(total, world_size)
+    return [base + (1 if r < rem else 0) for r in range(world_size)]
+
+
+def shard_range(total, world_size, rank):
+    sizes = shard_sizes(total, world_size)
+    start = sum(sizes[:rank])
+    return start, start + sizes[rank]
+
+
+def moment_planes(samples):
+    """samples (n, 1, H, W) complex -> (6, 1, H, W) float32 partial sums:
+    sum|x|, sum|x|^2, sum angle, sum angle^2, sum Re, sum Im  (helpers/metrics.py:77-92 semantics)."""
+    mag, ph = samples.abs().float(), samples.angle().float()
+    return torch.stack([mag.sum(0), (mag * mag).sum(0), ph.sum(0), (ph * ph).sum(0),
+                        samples.real.float().sum(0), samples.imag.float().sum(0)])
+
+
+def posterior_from_moments(m, n):
+    """-> dict(mag_mean, phase_mean, mag_std, phase_std, mean) (population std, as np.std)"""
+    mag_mean, ph_mean = m[0] / n, m[2] / n
+    return dict(mag_mean=mag_mean, phase_mean=ph_mean,
+                mag_std=(m[1] / n - mag_mean ** 2).clamp_min(0).sqrt(),
+                phase_std=(m[3] / n - ph_mean ** 2).clamp_min(0).sqrt(),
+                mean=torch.complex(m[4] / n, m[5] / n))
+
+
+def all_reduce_posterior(local_samples, total):
+    """one all-reduce of 6 planes (384 KiB at 128x128); works without an initialised process group (N=1)."""
+    m = moment_planes(local_samples)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(m, op=dist.ReduceOp.SUM)
+    return posterior_from_moments(m, total)

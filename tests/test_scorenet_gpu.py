@@ -1,0 +1,170 @@
+"""Score network + samplers on the GPU (HIP kernels through the C ABI) against the golden vectors the
+reference produced and against the CPU oracle.  fp32 tolerances stated per test."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import state_dict_from_golden
+from oracle import kspace, scorenet as oracle_net, ald as oracle_ald, metrics
+
+pytestmark = pytest.mark.gpu
+
+
+def tiny_config(ngf=4, num_classes=10, sigma_begin=1.0, sigma_end=0.01, device="cuda"):
+    return Namespace(
+        device=torch.device(device),
+        data=Namespace(channels=1, image_size=32, logit_transform=False, rescaled=False,
+                       uniform_dequantization=False, gaussian_dequantization=False),
+        model=Namespace(ngf=ngf, num_classes=num_classes, sigma_begin=sigma_begin, sigma_end=sigma_end,
+                        sigma_dist="geometric", normalization="InstanceNorm++", nonlinearity="elu", spec_norm=False),
+        recons=Namespace(sigma_dist="geometric", sigma_begin=sigma_begin, sigma_end=sigma_end,
+                         num_classes=num_classes),
+        sampling=Namespace(n_steps_each=3, step_lr=9e-7, final_only=True, denoise=True))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    assert torch.cuda.is_available()
+    from inverseproblemwithdiffusionmodel_amd.ncsn.models import layers, ncsnv2, normalization, ALD_optimizers, proximal_op
+    from inverseproblemwithdiffusionmodel_amd.ncsn.linear_transforms import undersampling_fourier
+    return Namespace(layers=layers, ncsnv2=ncsnv2, normalization=normalization, ald=ALD_optimizers,
+                     prox=proximal_op, uf=undersampling_fourier)
+
+
+def _load(module, g, prefix):
+    sd = state_dict_from_golden(g, prefix)
+    missing, unexpected = module.load_state_dict(sd, strict=True), None
+    return module.cuda()
+
+
+def test_instance_norm_module(pkg, golden):
+    g = golden("g07_layers")
+    m = _load(pkg.normalization.InstanceNorm2dPlus(6), g, "in")
+    y = m(torch.from_numpy(g["in_x"]).cuda()).cpu().numpy()
+    np.testing.assert_allclose(y, g["in_y"], atol=3e-6)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("rb_plain", dict(input_dim=6, output_dim=6, resample=None)),
+    ("rb_widen", dict(input_dim=6, output_dim=8, resample=None)),
+    ("rb_pool", dict(input_dim=6, output_dim=8, resample="down")),
+    ("rb_dil_down", dict(input_dim=6, output_dim=8, resample="down", dilation=2)),
+    ("rb_dil_same", dict(input_dim=6, output_dim=6, resample=None, dilation=4)),
+])
+def test_residual_block(pkg, golden, name, kw):
+    g = golden("g07_layers")
+    act = pkg.layers._Act("elu")
+    m = _load(pkg.layers.ResidualBlock(act=act, normalization=pkg.normalization.InstanceNorm2dPlus, **kw), g, name)
+    y = m(torch.from_numpy(g["in_x"]).cuda()).cpu().numpy()
+    np.testing.assert_allclose(y, g[name + "_y"], atol=1e-5)
+
+
+def test_refine_blocks(pkg, golden):
+    g = golden("g07_layers")
+    act = pkg.layers._Act("elu")
+    xa, xb = torch.from_numpy(g["rf_xa"]).cuda(), torch.from_numpy(g["rf_xb"]).cuda()
+    m = _load(pkg.layers.RefineBlock([6], 6, act=act, start=True), g, "rf_start")
+    np.testing.assert_allclose(m([xa], xa.shape[2:]).cpu().numpy(), g["rf_start_y"], atol=2e-5)
+    m = _load(pkg.layers.RefineBlock([6, 4], 5, act=act), g, "rf_two")
+    np.testing.assert_allclose(m([xa, xb], xa.shape[2:]).cpu().numpy(), g["rf_two_y"], atol=2e-5)
+    m = _load(pkg.layers.RefineBlock([6, 4], 6, act=act, end=True), g, "rf_end")
+    np.testing.assert_allclose(m([xa, xb], xa.shape[2:]).cpu().numpy(), g["rf_end_y"], atol=2e-5)
+
+
+@pytest.fixture(scope="module")
+def tiny_net(pkg, golden):
+    g = golden("g07_layers")
+    net = pkg.ncsnv2.NCSNv2Deepest(tiny_config())
+    net.load_state_dict(state_dict_from_golden(g, "net"), strict=True)
+    return net.cuda().eval()
+
+
+def test_tiny_ncsnv2_deepest(tiny_net, golden):
+    g = golden("g07_layers")
+    y = tiny_net(torch.from_numpy(g["net_x"]).cuda(), torch.from_numpy(g["net_labels"]).cuda()).cpu().numpy()
+    ref = g["net_y"]
+    assert np.abs(y - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_full_size_ncsnv2_deepest(pkg, golden):
+    """ACDC network (ngf 128, 94.1 M parameters) at 128x128 vs the reference's own forward."""
+    from inverseproblemwithdiffusionmodel_amd.synthetic import synth_state_dict
+    g = golden("g15_fullnet")
+    cfg = tiny_config(ngf=128, num_classes=2311, sigma_begin=348, sigma_end=0.01)
+    net = pkg.ncsnv2.NCSNv2Deepest(cfg)
+    keys = list(net.state_dict().keys())
+    assert keys == list(g["key_names"])                       # same 230 state-dict keys, same order
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=0)
+    net.load_state_dict(sd, strict=False)
+    net = net.cuda().eval()
+    y = net(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["labels"]).cuda()).cpu().numpy()
+    ref = g["y"]
+    assert np.abs(y - ref).max() <= 2e-4 * np.abs(ref).max()
+    assert metrics.nrmse(y, ref) < 1e-4
+
+
+class _Tape:
+    def __init__(self, tape):
+        self.tape, self.i = tape, 0
+
+    def __call__(self, like):
+        n = torch.from_numpy(self.tape[self.i])
+        self.i += 1
+        return n
+
+
+def _sense_sampler(pkg, tiny_net, golden, B=2):
+    g = golden("g08_ald")
+    op = pkg.uf.SENSE("exp", 4, 8, 0.04, (1, 32, 32), seed=0)
+    sigmas = torch.from_numpy(g["sigmas"]).cuda()
+    params = dict(n_steps_each=3, step_lr=9e-7, denoise=True, final_only=True)
+    meas = torch.from_numpy(g["measurement"])[:, :B].cuda()
+    sampler = pkg.ald.ALDInvSegProximalRealImag(pkg.prox.get_proximal("L2Penalty")(op), 1.0, "linear",
+                                                (B, 1, 32, 32), tiny_net, sigmas, params, tiny_config(), meas, op,
+                                                seg=None, device=torch.device("cuda"))
+    return g, sampler
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("tag", ["dc_visible", "script_default"])
+def test_ald_sense_trajectory_golden(pkg, tiny_net, golden, tag, use_graph):
+    """the reference's own ALDInvSegProximalRealImag trajectory (60 noisy steps + denoise) under the same
+    injected noise: NRMSE (reference definition) and SSIM of the magnitudes within 1e-3."""
+    g, sampler = _sense_sampler(pkg, tiny_net, golden)
+    tape = _Tape(g["noise"])
+    x = sampler(label=None, lamda=0.1, save_dir=None, lr_scaled=float(g[f"{tag}_lr_scaled"]), seg_mode="full",
+                noise_fn=tape, use_graph=use_graph)[0].numpy()
+    assert tape.i == 60
+    ref = g[f"{tag}_x"]
+    assert x.shape == ref.shape and x.dtype == np.complex64
+    for b in range(x.shape[0]):
+        assert metrics.nrmse(np.abs(x[b]), np.abs(ref[b])) < 1e-3
+        assert abs(metrics.ssim(np.abs(x[b, 0]), np.abs(ref[b, 0])) - 1.0) < 1e-3
+    np.testing.assert_allclose(x, ref, atol=1e-3)
+
+
+def test_ald_unconditional_golden(pkg, tiny_net, golden):
+    g = golden("g08_ald")
+    sigmas = torch.from_numpy(g["sigmas"]).cuda()
+    params = dict(n_steps_each=3, step_lr=float(g["uncond_step_lr"]), denoise=True, final_only=True)
+    sampler = pkg.ald.ALDUnconditionalSampler((2, 1, 32, 32), tiny_net, sigmas, params, tiny_config(),
+                                              device=torch.device("cuda"))
+    sampler.init_x_mod = lambda: torch.from_numpy(g["uncond_x0"]).cuda()
+    x = sampler(noise_fn=_Tape(g["uncond_noise"]))[0].numpy()
+    np.testing.assert_allclose(x, g["uncond_x"], atol=1e-3)
+    assert metrics.nrmse(x, g["uncond_x"]) < 1e-3
+
+
+def test_philox_run_is_shard_invariant(pkg, tiny_net, golden):
+    """4 samples on one rank == samples [0,2) and [2,4) on two ranks (global-sample-id Philox keys)."""
+    g, s4 = _sense_sampler(pkg, tiny_net, golden, B=2)
+    # build a 4-sample measurement by repeating the 2-sample one
+    s4.measurement = torch.cat([s4.measurement, s4.measurement], dim=1)
+    full = s4(lr_scaled=2e6, seed=123, sample_offset=0, n_levels=4)[0]
+    _, s2 = _sense_sampler(pkg, tiny_net, golden, B=2)
+    a = s2(lr_scaled=2e6, seed=123, sample_offset=0, n_levels=4)[0]
+    b = s2(lr_scaled=2e6, seed=123, sample_offset=2, n_levels=4)[0]
+    assert torch.equal(full[:2], a) and torch.equal(full[2:], b)
+    assert not torch.equal(a, b)
