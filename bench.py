@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Benchmark of the ALD reconstruction hot path (BASELINE.json metric: ALD reconstructions/sec, 128x128 complex,
+R=40, 4 coils) on N MI355X of one node.
+
+    python bench.py                       # N=1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload (SURVEY.md 8d, config 3 of BASELINE.json): 105 posterior samples block-partitioned over 8 GPUs
+= 14 on rank 0 and 13 on the others; for N < 8 every rank keeps that per-GPU share (rank 0: 14, others: 13),
+so the critical path per GPU is the same at every N ("weak" scaling) and N = 8 is exactly the 105-sample run.
+Score net NCSNv2Deepest (ngf 128, 94.1 M parameters, seeded random init), sigma 348 -> 0.01 geometric in
+2311 levels x 3 Langevin steps, step_lr 9e-7, L2Penalty proximal, final denoise; synthetic phantom k-space.
+
+One "step" = one Langevin iteration of a rank's whole sample batch: the score network on the (2B, 1, 128, 128)
+[real | imaginary] batch + the fused Langevin/SENSE-proximal kernel, replayed as one hipGraph.  A full
+reconstruction is 2311*3 = 6933 such iterations plus one denoising score evaluation (counted as a 6934th
+iteration); the iteration cost does not depend on the noise level (same launches, same shapes), so
+    value = total samples / (ms_per_step * 6934)
+with the timed steps strided evenly over the 6933-iteration schedule.  `--full` runs the entire schedule instead
+and reports the directly measured rate (takes ~6934/steps times longer).
+
+The JSON line also carries
+  roofline      fp32 MFMA roofline of the dominant kernel family (conv_mfma_kernel<...>, the dense 3x3/1x1
+                convolutions): algorithmic FLOPs of the 113 conv launches of one score evaluation divided by
+                their summed durations, measured with HIP events around every conv launch on the launch stream.
+  cpu_baseline  the CPU oracle (oracle/, a torch-CPU restatement pinned to the reference) timed on this host's
+                cores on a bounded slice of the same workload (1 sample, a few iterations), rank 0 / N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+L_LEVELS, N_EACH = 2311, 3
+ITER_PER_RECON = L_LEVELS * N_EACH + 1  # + the denoising score evaluation
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--full", action="store_true", help="run the whole 6933-iteration schedule + denoise")
+    ap.add_argument("--samples-rank0", type=int, default=14)
+    ap.add_argument("--samples-other", type=int, default=13)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU share of this process: affinity mask capped by the cgroup quota (a GPU box gives 16 per GPU)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, q // int(g.read())))
+        except Exception:
+            pass
+    return max(1, min(n, int(os.environ.get("IPDM_CPU_THREADS", 32))))
+
+
+def cpu_baseline(prob, n_iters):
+    """time the CPU oracle on 1 sample for n_iters Langevin+proximal iterations (after 1 warm-up iteration)."""
+    from oracle import scorenet as oracle_net, ald as oracle_ald
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads ...")
+    sd = {k: v.detach().cpu() for k, v in prob.scorenet.state_dict().items()}
+    meas = prob.measurement[:, :1].cpu().numpy()
+    maps, mask = prob.op.sens_maps.numpy(), prob.op.random_under_fourier.mask.numpy()
+    gen = torch.Generator().manual_seed(0)
+    noise = lambda like: torch.randn(like.shape, generator=gen)
+    score = lambda x, lab: oracle_net.ncsnv2_deepest(x, lab, sd)
+
+    def run(levels):
+        with torch.no_grad():
+            return oracle_ald.ald_sense_real_imag(score, prob.sigmas.cpu().numpy(), meas, maps, mask,
+                                                  prob.params["step_lr"], 1, 1.0, False, noise, n_levels=levels)
+    run(1)
+    log("cpu baseline warm-up done")
+    t0 = time.perf_counter()
+    run(n_iters)
+    dt = (time.perf_counter() - t0) / n_iters
+    return dict(value=1.0 / (dt * ITER_PER_RECON), unit="reconstructions/s", cores=cores, kind="port",
+                sample=f"1 sample x {n_iters} Langevin+proximal iterations (2 score evaluations each, {dt * 1e3:.0f} ms "
+                       f"per iteration) of the same 128x128 R=40 4-coil workload, extrapolated to {ITER_PER_RECON} "
+                       "iterations; torch-CPU fp32 oracle (oracle/), all host cores")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from inverseproblemwithdiffusionmodel_amd import engine, sharding
+
+    n_local = args.samples_rank0 if rank == 0 else args.samples_other
+    total = args.samples_rank0 + args.samples_other * (world - 1)
+    offset = 0 if rank == 0 else args.samples_rank0 + args.samples_other * (rank - 1)
+    prob = engine.build_problem(dev, n_local, R=40, H=128, W=128, num_sens=4, seed=0)
+    runner = engine.IterationRunner(prob, seed=0, sample_offset=offset, use_graph=not args.no_graph)
+    n_sched = runner.n_iterations                                   # 6933
+    log(f"rank {rank}: setup done, {n_local} local samples")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.full:
+        steps, warm = n_sched, 0
+        order = np.arange(n_sched)
+    else:
+        steps, warm = args.steps, args.warmup
+        order = (np.arange(warm + steps) * (n_sched // max(warm + steps, 1))) % n_sched   # strided over the schedule
+    for k in order[:warm]:
+        runner.run(int(k))
+    if warm == 0:
+        runner.run(0)                                                # capture outside the timed region
+    barrier()
+    t0 = time.perf_counter()
+    for k in order[warm:warm + steps]:
+        runner.run(int(k))
+    if args.full:                                                    # denoise: one more score evaluation
+        with torch.no_grad():
+            runner.st["labels"].fill_(L_LEVELS - 1)
+            prob.scorenet(runner.x, runner.st["labels"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    log(f"rank {rank}: {steps} steps in {elapsed:.3f} s")
+    finite = bool(torch.isfinite(runner.x).all())
+
+    # the one collective of the path: posterior moments of the current samples
+    post = sharding.all_reduce_posterior(runner.current(), total)
+    ms_per_step = elapsed * 1e3 / steps
+    if args.full:
+        value = total / elapsed
+    else:
+        value = total / (ms_per_step * 1e-3 * ITER_PER_RECON)
+
+    out = {
+        "metric": "ALD reconstructions/sec (128x128 complex, R=40, 4-coil)",
+        "value": value, "unit": "reconstructions/s", "n_gpus": world, "steps": steps, "warmup": warm,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "ACDC-style 128x128 complex SENSE R=40 4-coil ALD reconstruction, NCSNv2Deepest ngf=128 "
+                        "(94.1M params, seeded random init), sigma 348->0.01 x 2311 levels x 3 steps, L2Penalty, denoise; "
+                        f"{total} posterior samples = {args.samples_rank0} on rank 0 + {args.samples_other} per further "
+                        "rank (the 105-sample / 8-GPU partition of BASELINE config 3)",
+            "step": "one Langevin iteration of a rank's sample batch: score net on (2B,1,128,128) + fused "
+                    "Langevin/SENSE-proximal kernel, one hipGraph replay",
+            "iterations_per_reconstruction": ITER_PER_RECON,
+            "value_formula": "total_samples / elapsed" if args.full else
+                             "total_samples / (ms_per_step * iterations_per_reconstruction)",
+            "samples_total": total, "samples_this_rank": n_local, "parallelism": f"sample-sharded x{world}",
+            "hip_graph": not args.no_graph, "state_finite": finite,
+            "posterior_mag_mean": float(post["mag_mean"].mean()),
+        },
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel family: per-launch HIP events around every conv of one forward
+        x = runner.x.clone()
+        labels = runner.st["labels"].clone()
+        engine.conv_census(prob.scorenet, x, labels)                 # warm
+        reps = [engine.conv_census(prob.scorenet, x, labels) for _ in range(3)]
+        flops = sum(r["flops"] for r in reps[0])
+        conv_ms = float(np.median([sum(r["ms"] for r in rep) for rep in reps]))
+        log(f"conv census: {len(reps[0])} launches, {conv_ms:.2f} ms, {flops / 1e12:.3f} TFLOP per step")
+        achieved = flops / (conv_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(REPO, "profiles", "conv_hbm_traffic.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        out["roofline"] = {
+            "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+            "kernel": "conv_mfma_kernel<...> (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv)",
+            "launches_per_step": len(reps[0]), "avg_launch_ms": conv_ms / len(reps[0]),
+            "algorithmic_flops_per_step": flops, "conv_ms_per_step": conv_ms,
+            "conv_share_of_step": conv_ms / ms_per_step,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

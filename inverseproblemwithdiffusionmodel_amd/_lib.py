@@ -6,6 +6,11 @@ or ``__graft_entry__.build()``), and every op raises when handed a tensor that d
 """
 import ctypes
 import os
+
+import torch  # noqa: F401  -- MUST precede the dlopen below: libipdm.so then binds to the HIP runtime that
+#                              PyTorch-ROCm already loaded (its bundled libamdhip64), so both share one
+#                              runtime, device context and stream table.  Loading /opt/rocm's copy first
+#                              leaves torch and the kernels on two different runtimes ("no device", error 100).
 from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

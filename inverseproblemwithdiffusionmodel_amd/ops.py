@@ -9,6 +9,8 @@ from . import _lib
 from ._lib import call, P
 
 ACT_NONE, ACT_ELU, ACT_RELU, ACT_LRELU02, ACT_SWISH = 0, 1, 2, 3, 4
+CONV_TRACE = None     # set to a list by engine.conv_census(): per-launch shapes + HIP events
+
 ACT_CODES = {"none": ACT_NONE, None: ACT_NONE, "elu": ACT_ELU, "relu": ACT_RELU, "lrelu": ACT_LRELU02,
              "swish": ACT_SWISH}
 
@@ -256,6 +258,12 @@ def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1,
     k = {1: 1, 9: 3}[kk]
     oh, ow = (H // 2, W // 2) if pool2 else (H, W)
     out = torch.empty((B, Cout, oh, ow), dtype=torch.float32, device=x.device) if out is None else out
+    if CONV_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("ipdm_conv2d_f32", _ptr(x), _ptr(wt), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
          B, Cin, Cout, H, W, k, dilation, int(bool(pool2)), _stream())
+    if CONV_TRACE is not None:
+        e1.record()
+        CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, dil=dilation, e0=e0, e1=e1))
     return out
