@@ -152,9 +152,9 @@ int ipdm_div_sigma_f32(const float* x, const float* sigmas, const int64_t* label
 int ipdm_maxpool5_f32(const float* x, float* y, int planes, int H, int W, void* stream);
 /* 2x2 mean pooling (ConvMeanPool's tail) [planes][H][W] -> [planes][H/2][W/2]; H, W even */
 int ipdm_meanpool2_f32(const float* x, float* y, int planes, int H, int W, void* stream);
-/* bilinear resize, align_corners=True: out (+)= resize(x); accumulate != 0 adds into out */
+/* bilinear resize, align_corners=True: out = act(resize(x) [+ out]); accumulate != 0 adds the previous out */
 int ipdm_bilinear_f32(const float* x, float* out, int planes, int in_h, int in_w, int out_h, int out_w,
-                      int accumulate, void* stream);
+                      int accumulate, int act /* applied to the value written */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense 3x3 / 1x1 convolution, float32 MFMA implicit GEMM (reference: torch.nn.Conv2d call sites in
@@ -162,11 +162,14 @@ int ipdm_bilinear_f32(const float* x, float* out, int planes, int in_h, int in_w
  *   out[b,co] = bias[co] + sum_ci W[co,ci] * pre(x[b,ci])  (+ residual[b,co])
  *   pre(v) = act((v - mu)*scale + shift) when coef != NULL (fused InstanceNorm2dPlus), else act(v)
  * wt is the weight repacked by ipdm_conv_pack_weight_f32: [k*k][Cin][Cout].
+ * out_act (optional) receives act_out(out): the activated copy the NEXT convolution consumes (RCU / CRP chains
+ * apply the non-linearity before every conv; producing it once in the epilogue is cheaper than activating in
+ * each consumer's prologue).  out may be NULL when only the activated copy is needed.
  * pool2 != 0 additionally applies the 2x2 mean (ConvMeanPool) in the epilogue: out is [B][Cout][H/2][W/2].
  * ---------------------------------------------------------------------------------------------- */
 int ipdm_conv_pack_weight_f32(const float* w /* [Cout][Cin][k][k] */, float* wt, int Cout, int Cin, int k, void* stream);
 int ipdm_conv2d_f32(const float* x, const float* wt, const float* bias, const float* coef, int act,
-                    const float* residual, float* out,
+                    const float* residual, float* out, float* out_act, int act_out,
                     int B, int Cin, int Cout, int H, int W, int k, int dilation, int pool2, void* stream);
 
 #ifdef __cplusplus

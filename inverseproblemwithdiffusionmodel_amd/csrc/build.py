@@ -39,7 +39,11 @@ def build(force=False, verbose=False):
         obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+            flags = list(FLAGS)
+            if os.path.basename(src).startswith("conv"):
+                # the MFMA convolution is an fma chain by construction; let its prologue VALU math fuse too
+                flags[flags.index("-ffp-contract=off")] = "-ffp-contract=fast"
+            jobs.append([HIPCC, *flags, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void meanpool2_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ x, float* out, int64_t n_out, int ih,
-                                                       int iw, int oh, int ow, float sh, float sw, int accumulate) {
+                                                       int iw, int oh, int ow, float sh, float sw, int accumulate, int act) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * 256) {
     int ox = (int)(i % ow);
     int64_t t = i / ow;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__
     const float* p = x + plane * (int64_t)ih * iw;
     float v = ly0 * (lx0 * p[y0 * iw + x0] + lx1 * p[y0 * iw + x0 + xp]) +
               ly1 * (lx0 * p[(y0 + yp) * iw + x0] + lx1 * p[(y0 + yp) * iw + x0 + xp]);
-    out[i] = accumulate ? out[i] + v : v;
+    out[i] = ipdm_act(accumulate ? out[i] + v : v, act);
   }
 }
 
@@ -320,7 +320,7 @@ extern "C" int ipdm_meanpool2_f32(const float* x, float* y, int planes, int H, i
 }
 
 extern "C" int ipdm_bilinear_f32(const float* x, float* out, int planes, int in_h, int in_w, int out_h, int out_w,
-                                 int accumulate, void* stream) {
+                                 int accumulate, int act, void* stream) {
   IPDM_REQUIRE(planes >= 0 && in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0);
   if (planes == 0) return IPDM_OK;
   IPDM_REQUIRE(x && out);
@@ -328,6 +328,6 @@ extern "C" int ipdm_bilinear_f32(const float* x, float* out, int planes, int in_
   float sw = out_w > 1 ? (float)(in_w - 1) / (float)(out_w - 1) : 0.f;
   int64_t n_out = (int64_t)planes * out_h * out_w;
   hipLaunchKernelGGL(bilinear_kernel, dim3(ipdm_ew_grid(n_out, 256)), dim3(256), 0, ipdm_stream(stream), x, out,
-                     (long long)n_out, in_h, in_w, out_h, out_w, sh, sw, accumulate);
+                     (long long)n_out, in_h, in_w, out_h, out_w, sh, sw, accumulate, act);
   return ipdm_launch_status();
 }

@@ -3,9 +3,11 @@
 RCUBlock :112-134, MSFBlock :165-184, RefineBlock :214-249, ConvMeanPool :291-313, ResidualBlock :401-456).
 
 Same parameter names / state-dict keys as the reference, different execution: every block is a short
-chain of libipdm.so launches.  Normalisation + activation are folded into the next convolution's input
-staging, bias / residual adds into its epilogue; the 5x5 max-pool, 2x2 mean-pool and bilinear
-accumulate are single kernels."""
+chain of libipdm.so launches.  Bias and residual adds live in the convolution epilogue, which can also
+emit the ACTIVATED copy of its result: the RCU / CRP chains (`x = act(x); x = conv(x)` over and over) then
+never run a separate activation pass -- blocks hand each other (raw, activated) pairs.  InstanceNorm++ +
+ELU in front of the ResidualBlock convolutions is one fused affine+activation kernel; the 5x5 max-pool,
+2x2 mean-pool and bilinear accumulate(+activation) are single kernels."""
 from functools import partial
 
 import torch
@@ -69,9 +71,9 @@ class Conv2d(nn.Module):
             self._packed_version = v
         return self._packed
 
-    def forward(self, x, coef=None, act=ops.ACT_NONE, residual=None, out=None):
+    def forward(self, x, coef=None, act=ops.ACT_NONE, residual=None, out=None, act_out=ops.ACT_NONE, raw=True):
         return ops.conv2d(x, self.packed(), None if self.bias is None else self.bias.data, coef, act, residual,
-                          self.dilation, out=out)
+                          self.dilation, out=out, act_out=act_out, raw=raw)
 
 
 def conv1x1(in_planes, out_planes, stride=1, bias=True, spec_norm=False):
@@ -96,8 +98,8 @@ class ConvMeanPool(nn.Module):
             raise NotImplementedError("adjust_padding / spec_norm are unused by every shipped config")
         self.conv = Conv2d(input_dim, output_dim, kernel_size, bias=biases)
 
-    def forward(self, inputs, coef=None, act=ops.ACT_NONE):
-        return ops.meanpool2(self.conv(inputs, coef, act))
+    def forward(self, inputs):
+        return ops.meanpool2(self.conv(inputs))
 
 
 class CRPBlock(nn.Module):
@@ -110,17 +112,23 @@ class CRPBlock(nn.Module):
         self.n_stages = n_stages
         self.act = act
 
-    def forward(self, x):
-        x = ops.act(x, _act_code(self.act))
-        path = x
+    def forward(self, x, x_act=None, want_act=False):
+        """reference: x = act(x); path = x; repeat: path = conv(maxpool(path)); x = path + x.
+        Takes the already-activated input when the producer emitted it; returns (x, act(x) or None)."""
+        code = _act_code(self.act)
+        x = x_act if x_act is not None else ops.act(x, code)
+        path, out_act = x, None
         for i in range(self.n_stages):
             pooled = ops.maxpool5(path)
-            if i == self.n_stages - 1:
-                x = self.convs[i](pooled, residual=x)          # x = conv(pool(path)) + x in one launch
+            if i == self.n_stages - 1:                       # x = conv(pool(path)) + x in one launch
+                if want_act:
+                    x, out_act = self.convs[i](pooled, residual=x, act_out=code)
+                else:
+                    x = self.convs[i](pooled, residual=x)
             else:
                 path = self.convs[i](pooled)
                 x = ops.add(path, x)
-        return x
+        return x, out_act
 
 
 class RCUBlock(nn.Module):
@@ -135,14 +143,22 @@ class RCUBlock(nn.Module):
         self.n_stages = n_stages
         self.act = act
 
-    def forward(self, x):
+    def forward(self, x, x_act=None, want_act=False):
+        """reference: per block  residual = x; (x = act(x); x = conv(x)) x n_stages; x += residual.
+        Inner stages only ever feed the next activation, so they write just the activated copy."""
         code = _act_code(self.act)
         for i in range(self.n_blocks):
             residual = x
+            a = x_act if x_act is not None else ops.act(x, code)
             for j in range(self.n_stages):
                 conv = getattr(self, '{}_{}_conv'.format(i + 1, j + 1))
-                x = conv(x, act=code, residual=residual if j == self.n_stages - 1 else None)
-        return x
+                if j < self.n_stages - 1:
+                    _, a = conv(a, act_out=code, raw=False)
+                elif i < self.n_blocks - 1 or want_act:
+                    x, x_act = conv(a, residual=residual, act_out=code)
+                else:
+                    x, x_act = conv(a, residual=residual), None
+        return x, x_act
 
 
 class MSFBlock(nn.Module):
@@ -152,16 +168,21 @@ class MSFBlock(nn.Module):
         self.convs = nn.ModuleList([conv3x3(p, features, bias=True, spec_norm=spec_norm) for p in in_planes])
         self.features = features
 
-    def forward(self, xs, shape):
+    def forward(self, xs, shape, act_out=ops.ACT_NONE):
+        """sum_i bilinear(conv_i(xs[i]));  act_out: return act(sum) instead (all the following CRP block needs)"""
         shape = tuple(int(s) for s in shape)
         sums = None
+        n = len(self.convs)
         for i, conv in enumerate(self.convs):
-            same = tuple(xs[i].shape[2:]) == shape
-            if same:
-                sums = conv(xs[i], residual=sums)              # bilinear resize to the same size is exact
+            last_act = act_out if i == n - 1 else ops.ACT_NONE
+            if tuple(xs[i].shape[2:]) == shape:                   # bilinear resize to the same size is exact
+                if last_act != ops.ACT_NONE:
+                    _, sums = conv(xs[i], residual=sums, act_out=last_act, raw=False)
+                else:
+                    sums = conv(xs[i], residual=sums)
             else:
                 h = conv(xs[i])
-                sums = ops.bilinear(h, shape, out=sums, accumulate=sums is not None)
+                sums = ops.bilinear(h, shape, out=sums, accumulate=sums is not None, act=last_act)
         return sums
 
 
@@ -176,13 +197,23 @@ class RefineBlock(nn.Module):
         if not start:
             self.msf = MSFBlock(in_planes, features, spec_norm=spec_norm)
         self.crp = CRPBlock(features, 2, act, maxpool=maxpool, spec_norm=spec_norm)
+        self.act = act
 
-    def forward(self, xs, output_shape):
+    def forward(self, xs, output_shape, xs_act=None, want_act=False):
+        """xs: raw inputs; xs_act: their activated copies where a producer emitted them (else None entries).
+        Returns the raw output, or (raw, activated) when want_act."""
         assert isinstance(xs, (tuple, list))
-        hs = [self.adapt_convs[i](xs[i]) for i in range(len(xs))]
-        h = self.msf(hs, output_shape) if self.n_blocks > 1 else hs[0]
-        h = self.crp(h)
-        return self.output_convs(h)
+        code = _act_code(self.act)
+        xs_act = [None] * len(xs) if xs_act is None else xs_act
+        single = self.n_blocks == 1
+        hs = [self.adapt_convs[i](xs[i], xs_act[i], want_act=single) for i in range(len(xs))]
+        if single:
+            h, h_act = self.crp(hs[0][0], hs[0][1], want_act=True)
+        else:
+            a = self.msf([h[0] for h in hs], output_shape, act_out=code)
+            h, h_act = self.crp(None, a, want_act=True)
+        out, out_act = self.output_convs(h, h_act, want_act=want_act)
+        return (out, out_act) if want_act else out
 
 
 class ResidualBlock(nn.Module):
@@ -223,14 +254,18 @@ class ResidualBlock(nn.Module):
             self.shortcut = conv_shortcut(input_dim, output_dim)
         self.normalize1 = normalization(input_dim)
 
-    def forward(self, x):
+    def forward(self, x, want_act=False):
+        """norm -> act -> conv1 -> norm -> act -> conv2 (+ shortcut).  want_act: also return act(out)."""
         code = _act_code(self.non_linearity)
-        h = self.conv1(x, self.normalize1.coef(x), code)
-        coef2 = self.normalize2.coef(h)
+        h = self.conv1(self.normalize1(x, code))
+        a2 = self.normalize2(h, code)
         if self.output_dim == self.input_dim and self.resample is None:
             shortcut = x
         else:
             shortcut = self.shortcut(x)
         if isinstance(self.conv2, ConvMeanPool):
-            return ops.add(shortcut, self.conv2(h, coef2, code))
-        return self.conv2(h, coef2, code, residual=shortcut)
+            out = ops.add(shortcut, self.conv2(a2))
+            return (out, ops.act(out, code)) if want_act else out
+        if want_act:
+            return self.conv2(a2, residual=shortcut, act_out=code)
+        return self.conv2(a2, residual=shortcut)

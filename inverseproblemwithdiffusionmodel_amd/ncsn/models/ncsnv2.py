@@ -23,8 +23,10 @@ class _NCSNv2Base(nn.Module):
         self._in_coef = {}
 
     def _compute_cond_module(self, module, x):
-        for m in module:
-            x = m(x)
+        """a res stage; its last block also emits the activated copy the RefineNet branch starts from"""
+        n = len(module)
+        for i, m in enumerate(module):
+            x = m(x, want_act=(i == n - 1))
         return x
 
     def _stage(self, cin, cout, resample=None, dilation=None):
@@ -47,8 +49,12 @@ class _NCSNv2Base(nn.Module):
         return self.begin_conv(x)
 
     def _end(self, output, x, y):
-        output = self.end_conv(output, self.normalizer.coef(output), self.act.code)
+        output = self.end_conv(self.normalizer(output, self.act.code))
         return ops.div_sigma(output, self.sigmas, y.to(torch.int64))
+
+    @staticmethod
+    def _refine(block, pairs, shape, want_act=True):
+        return block([p[0] for p in pairs], shape, [p[1] for p in pairs], want_act=want_act)
 
 
 class NCSNv2Deepest(_NCSNv2Base):
@@ -74,17 +80,17 @@ class NCSNv2Deepest(_NCSNv2Base):
     def forward(self, x, y):
         output = self._begin(x)
         layer1 = self._compute_cond_module(self.res1, output)
-        layer2 = self._compute_cond_module(self.res2, layer1)
-        layer3 = self._compute_cond_module(self.res3, layer2)
-        layer31 = self._compute_cond_module(self.res31, layer3)
-        layer4 = self._compute_cond_module(self.res4, layer31)
-        layer5 = self._compute_cond_module(self.res5, layer4)
-        ref1 = self.refine1([layer5], layer5.shape[2:])
-        ref2 = self.refine2([layer4, ref1], layer4.shape[2:])
-        ref31 = self.refine31([layer31, ref2], layer31.shape[2:])
-        ref3 = self.refine3([layer3, ref31], layer3.shape[2:])
-        ref4 = self.refine4([layer2, ref3], layer2.shape[2:])
-        output = self.refine5([layer1, ref4], layer1.shape[2:])
+        layer2 = self._compute_cond_module(self.res2, layer1[0])
+        layer3 = self._compute_cond_module(self.res3, layer2[0])
+        layer31 = self._compute_cond_module(self.res31, layer3[0])
+        layer4 = self._compute_cond_module(self.res4, layer31[0])
+        layer5 = self._compute_cond_module(self.res5, layer4[0])
+        ref1 = self._refine(self.refine1, [layer5], layer5[0].shape[2:])
+        ref2 = self._refine(self.refine2, [layer4, ref1], layer4[0].shape[2:])
+        ref31 = self._refine(self.refine31, [layer31, ref2], layer31[0].shape[2:])
+        ref3 = self._refine(self.refine3, [layer3, ref31], layer3[0].shape[2:])
+        ref4 = self._refine(self.refine4, [layer2, ref3], layer2[0].shape[2:])
+        output = self._refine(self.refine5, [layer1, ref4], layer1[0].shape[2:], want_act=False)
         return self._end(output, x, y)
 
 
@@ -109,15 +115,15 @@ class NCSNv2Deeper(_NCSNv2Base):
     def forward(self, x, y):
         output = self._begin(x)
         layer1 = self._compute_cond_module(self.res1, output)
-        layer2 = self._compute_cond_module(self.res2, layer1)
-        layer3 = self._compute_cond_module(self.res3, layer2)
-        layer4 = self._compute_cond_module(self.res4, layer3)
-        layer5 = self._compute_cond_module(self.res5, layer4)
-        ref1 = self.refine1([layer5], layer5.shape[2:])
-        ref2 = self.refine2([layer4, ref1], layer4.shape[2:])
-        ref3 = self.refine3([layer3, ref2], layer3.shape[2:])
-        ref4 = self.refine4([layer2, ref3], layer2.shape[2:])
-        output = self.refine5([layer1, ref4], layer1.shape[2:])
+        layer2 = self._compute_cond_module(self.res2, layer1[0])
+        layer3 = self._compute_cond_module(self.res3, layer2[0])
+        layer4 = self._compute_cond_module(self.res4, layer3[0])
+        layer5 = self._compute_cond_module(self.res5, layer4[0])
+        ref1 = self._refine(self.refine1, [layer5], layer5[0].shape[2:])
+        ref2 = self._refine(self.refine2, [layer4, ref1], layer4[0].shape[2:])
+        ref3 = self._refine(self.refine3, [layer3, ref2], layer3[0].shape[2:])
+        ref4 = self._refine(self.refine4, [layer2, ref3], layer2[0].shape[2:])
+        output = self._refine(self.refine5, [layer1, ref4], layer1[0].shape[2:], want_act=False)
         return self._end(output, x, y)
 
 
@@ -142,11 +148,11 @@ class NCSNv2(_NCSNv2Base):
     def forward(self, x, y):
         output = self._begin(x)
         layer1 = self._compute_cond_module(self.res1, output)
-        layer2 = self._compute_cond_module(self.res2, layer1)
-        layer3 = self._compute_cond_module(self.res3, layer2)
-        layer4 = self._compute_cond_module(self.res4, layer3)
-        ref1 = self.refine1([layer4], layer4.shape[2:])
-        ref2 = self.refine2([layer3, ref1], layer3.shape[2:])
-        ref3 = self.refine3([layer2, ref2], layer2.shape[2:])
-        output = self.refine4([layer1, ref3], layer1.shape[2:])
+        layer2 = self._compute_cond_module(self.res2, layer1[0])
+        layer3 = self._compute_cond_module(self.res3, layer2[0])
+        layer4 = self._compute_cond_module(self.res4, layer3[0])
+        ref1 = self._refine(self.refine1, [layer4], layer4[0].shape[2:])
+        ref2 = self._refine(self.refine2, [layer3, ref1], layer3[0].shape[2:])
+        ref3 = self._refine(self.refine3, [layer2, ref2], layer2[0].shape[2:])
+        output = self._refine(self.refine4, [layer1, ref3], layer1[0].shape[2:], want_act=False)
         return self._end(output, x, y)

@@ -226,14 +226,14 @@ def meanpool2(x):
     return out
 
 
-def bilinear(x, size, out=None, accumulate=False):
+def bilinear(x, size, out=None, accumulate=False, act=ACT_NONE):
     x = _gpu(x, torch.float32, "x")
     B, C, H, W = x.shape
     oh, ow = int(size[0]), int(size[1])
     if out is None:
         out = torch.empty((B, C, oh, ow), dtype=torch.float32, device=x.device)
         accumulate = False
-    call("ipdm_bilinear_f32", _ptr(x), _ptr(out), B * C, H, W, oh, ow, int(bool(accumulate)), _stream())
+    call("ipdm_bilinear_f32", _ptr(x), _ptr(out), B * C, H, W, oh, ow, int(bool(accumulate)), act, _stream())
     return out
 
 
@@ -247,9 +247,12 @@ def conv_pack_weight(w):
     return wt
 
 
-def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, pool2=False, out=None):
-    """x [B,Cin,H,W]; wt packed [k*k,Cin,Cout]; optional fused InstanceNorm++ coefficients / activation on the
-    input, bias, residual add and 2x2 mean-pool on the output."""
+def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, pool2=False, out=None,
+           act_out=ACT_NONE, raw=True):
+    """x [B,Cin,H,W]; wt packed [k*k,Cin,Cout].  Input side: optional InstanceNorm++ coefficients / activation.
+    Output side: bias, residual add; act_out != NONE additionally returns the activated copy act_out(result)
+    (raw=False: ONLY the activated copy is produced).  Returns out, or (out, out_act) when act_out is set
+    (out is None when raw=False)."""
     x = _gpu(x, torch.float32, "x")
     B, Cin, H, W = x.shape
     kk, Cin_w, Cout = wt.shape
@@ -257,13 +260,20 @@ def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1,
         raise ValueError(f"conv2d: weight Cin {Cin_w} != input Cin {Cin}")
     k = {1: 1, 9: 3}[kk]
     oh, ow = (H // 2, W // 2) if pool2 else (H, W)
-    out = torch.empty((B, Cout, oh, ow), dtype=torch.float32, device=x.device) if out is None else out
+    want_act = act_out != ACT_NONE
+    if not raw and not want_act:
+        raise ValueError("conv2d: raw=False needs act_out")
+    if raw:
+        out = torch.empty((B, Cout, oh, ow), dtype=torch.float32, device=x.device) if out is None else out
+    else:
+        out = None
+    out_act = torch.empty((B, Cout, oh, ow), dtype=torch.float32, device=x.device) if want_act else None
     if CONV_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("ipdm_conv2d_f32", _ptr(x), _ptr(wt), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
-         B, Cin, Cout, H, W, k, dilation, int(bool(pool2)), _stream())
+    call("ipdm_conv2d_f32", _ptr(x), _ptr(wt), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out), _ptr(out_act),
+         act_out, B, Cin, Cout, H, W, k, dilation, int(bool(pool2)), _stream())
     if CONV_TRACE is not None:
         e1.record()
         CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, dil=dilation, e0=e0, e1=e1))
-    return out
+    return (out, out_act) if want_act else out

@@ -10,6 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from inverseproblemwithdiffusionmodel_amd import ops
 
 B = int(os.environ.get("BENCH_B", 28))
+ONLY = os.environ.get("BENCH_ONLY")          # e.g. "0,1,2": indices into SHAPES
+NO_MIOPEN = os.environ.get("BENCH_NO_MIOPEN") == "1"
+FUSED = os.environ.get("BENCH_FUSED") == "1"   # ELU + InstanceNorm++ coefficients on the input, residual on the output
 SHAPES = [  # (count per forward, Cin, Cout, H, dil)
     (18, 128, 128, 128, 1), (9, 128, 128, 64, 1), (8, 256, 256, 64, 1), (17, 256, 256, 32, 1),
     (25, 256, 256, 16, 1), (16, 512, 512, 16, 2), (5, 512, 512, 16, 4), (1, 128, 256, 128, 1),
@@ -29,15 +32,23 @@ def timeit(fn, iters=10):
 
 tot_m = tot_o = 0.0
 print(f"B={B}  (fp32 MFMA peak 157.3 TFLOP/s)")
-for cnt, ci, co, hw, dil in SHAPES:
+for idx, (cnt, ci, co, hw, dil) in enumerate(SHAPES):
+    if ONLY and str(idx) not in ONLY.split(","):
+        continue
     x = torch.randn(B, ci, hw, hw, device="cuda")
     w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
     bias = torch.randn(co, device="cuda")
     wt = ops.conv_pack_weight(w)
     out = torch.empty(B, co, hw, hw, device="cuda")
     flop = 2.0 * B * hw * hw * ci * co * 9
-    t_m = timeit(lambda: F.conv2d(x, w, bias, padding=dil, dilation=dil))
-    t_o = timeit(lambda: ops.conv2d(x, wt, bias, dilation=dil, out=out))
+    t_m = 1e9 if NO_MIOPEN else timeit(lambda: F.conv2d(x, w, bias, padding=dil, dilation=dil))
+    if FUSED and ci > 1:
+        coef = torch.randn(B, ci, 3, device="cuda")
+        res = torch.randn(B, co, hw, hw, device="cuda")
+        t_o = timeit(lambda: ops.conv2d(x, wt, bias, coef, ops.ACT_ELU, res, dilation=dil, out=out))
+        ops.conv2d(x, wt, bias, dilation=dil, out=out)
+    else:
+        t_o = timeit(lambda: ops.conv2d(x, wt, bias, dilation=dil, out=out))
     err = (out - F.conv2d(x, w, bias, padding=dil, dilation=dil)).abs().max().item()
     tot_m += cnt * t_m; tot_o += cnt * t_o
     print(f"{cnt:3d}x {ci:4d}->{co:4d} @{hw:3d}^2 d{dil}: miopen {t_m:8.3f} ms {flop / t_m / 1e9:7.1f} TF | "

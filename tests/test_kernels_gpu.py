@@ -332,3 +332,28 @@ def test_conv2d_mfma_layout_identity(ops):
     got = ops.conv2d(x.cuda(), ops.conv_pack_weight(w.cuda())).cpu()
     want = x[:, [(c * 7 + 3) % Cin for c in range(Cout)]]
     assert torch.equal(got, want)
+
+
+def test_conv2d_activated_second_output(ops):
+    """epilogue emits act(result) next to (or instead of) the raw result"""
+    gen = torch.Generator().manual_seed(14)
+    x = torch.randn(2, 64, 16, 32, generator=gen)
+    w = torch.randn(64, 64, 3, 3, generator=gen) / 24
+    resid = torch.randn(2, 64, 16, 32, generator=gen)
+    wt = ops.conv_pack_weight(w.cuda())
+    want = F.conv2d(x.double(), w.double(), padding=1) + resid.double()
+    raw, act = ops.conv2d(x.cuda(), wt, residual=resid.cuda(), act_out=ops.ACT_ELU)
+    assert (raw.cpu().double() - want).abs().max() < 2e-5
+    assert (act.cpu().double() - F.elu(want)).abs().max() < 2e-5
+    none, act2 = ops.conv2d(x.cuda(), wt, residual=resid.cuda(), act_out=ops.ACT_ELU, raw=False)
+    assert none is None and torch.equal(act2, act)
+    # ELU accuracy of the branch-free form around zero (series) and for large negatives (exp)
+    v = torch.tensor([-20.0, -3.0, -0.07, -0.0625, -0.06, -1e-3, -1e-6, 0.0, 1e-6, 2.0])
+    xin = torch.zeros(1, 32, 1, 32)
+    xin[0, 0, 0, :10] = v
+    wid = torch.zeros(32, 32, 1, 1)
+    wid[0, 0, 0, 0] = 1.0
+    _, e = ops.conv2d(xin.cuda(), ops.conv_pack_weight(wid.cuda()), act_out=ops.ACT_ELU)
+    got = e.cpu()[0, 0, 0, :10].double()
+    ref = F.elu(v.double())
+    assert ((got - ref).abs() <= 2e-7 + 2e-6 * ref.abs()).all()
