@@ -145,7 +145,7 @@ int ipdm_act_f32(const float* x, float* y, int64_t n, int act, void* stream);
 int ipdm_scale_shift_f32(const float* x, float* y, int64_t n, float a, float b, void* stream);
 /* out = x + y (out may alias either) */
 int ipdm_add_f32(const float* x, const float* y, float* out, int64_t n, void* stream);
-/* out[b,...] = x[b,...] * (inv ? 1/sigmas[labels[b]] : sigmas[labels[b]]^2-style scale is done by caller) */
+/* out[b,...] = x[b,...] / sigmas[labels[b]];  labels == NULL: out[b,...] = x[b,...] / sigmas[b] */
 int ipdm_div_sigma_f32(const float* x, const float* sigmas, const int64_t* labels, float* out,
                        int B, int64_t sample_elems, void* stream);
 /* MaxPool2d(kernel 5, stride 1, padding 2) on [planes][H][W] */
@@ -155,6 +155,29 @@ int ipdm_meanpool2_f32(const float* x, float* y, int planes, int H, int W, void*
 /* bilinear resize, align_corners=True: out = act(resize(x) [+ out]); accumulate != 0 adds the previous out */
 int ipdm_bilinear_f32(const float* x, float* out, int planes, int in_h, int in_w, int out_h, int out_w,
                       int accumulate, int act /* applied to the value written */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * NCSN++ / predictor-corrector extras (reference: torch.nn.GroupNorm(eps 1e-6) in models/layerspp.py:66,219
+ * and models/ncsnpp.py:194; torch.nn.Linear models/ncsnpp.py:85-90; AttnBlockpp.forward models/layerspp.py:75-91;
+ * skip_rescale (x + h)/sqrt(2) models/layerspp.py:88-91,271-274; ReverseDiffusionPredictor / LangevinCorrector
+ * update arithmetic sde/sampling.py:200-205, 267-287).
+ * ---------------------------------------------------------------------------------------------- */
+/* GroupNorm as per-(b,c) coefficients (mu, weight*rstd, bias) for ipdm_affine_act_f32 / the conv prologue */
+int ipdm_groupnorm_coef_f32(const float* x, const float* weight, const float* bias, float* coef,
+                            int B, int C, int HW, int G, float eps, void* stream);
+/* y[b][o] = bias[o] + sum_i act(x[b][i]) * W[o][i]   (torch.nn.Linear weight layout [Out][In]) */
+int ipdm_linear_f32(const float* x, const float* W, const float* bias, float* y, int B, int In, int Out,
+                    int act, void* stream);
+/* out[b,:,i] = sum_j softmax_j(scale * q[b,:,i].k[b,:,j]) v[b,:,j]   q,k,v,out [B][C][N] */
+int ipdm_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int C, int N,
+                       float scale, void* stream);
+/* out = a*x + b*y */
+int ipdm_axpby_f32(const float* x, const float* y, float* out, int64_t n, float a, float b, void* stream);
+/* out[s] = x[s] + a[s]*y[s] + c[s]*z[s] with per-sample device coefficients a, c [n_samples]; z/c may be NULL */
+int ipdm_sample_axpy2_f32(const float* x, const float* y, const float* z, const float* a, const float* c,
+                          float* out, int n_samples, int64_t sample_elems, void* stream);
+/* norms[s] = ||x[s]||_2 */
+int ipdm_sample_norm_f32(const float* x, float* norms, int n_samples, int64_t sample_elems, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense 3x3 / 1x1 convolution, float32 MFMA implicit GEMM (reference: torch.nn.Conv2d call sites in

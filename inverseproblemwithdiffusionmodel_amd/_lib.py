@@ -43,6 +43,12 @@ SIGNATURES = {
     "ipdm_maxpool5_f32": [P, P, c_int, c_int, c_int, P],
     "ipdm_meanpool2_f32": [P, P, c_int, c_int, c_int, P],
     "ipdm_bilinear_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "ipdm_groupnorm_coef_f32": [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
+    "ipdm_linear_f32": [P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "ipdm_attention_f32": [P, P, P, P, c_int, c_int, c_int, c_float, P],
+    "ipdm_axpby_f32": [P, P, P, c_int64, c_float, c_float, P],
+    "ipdm_sample_axpy2_f32": [P, P, P, P, P, P, c_int, c_int64, P],
+    "ipdm_sample_norm_f32": [P, P, c_int, c_int64, P],
     "ipdm_conv_pack_weight_f32": [P, P, c_int, c_int, c_int, P],
     "ipdm_conv2d_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 8 + [P],
 }

@@ -1,0 +1,206 @@
+// Small kernels the NCSN++ score network and the predictor-corrector samplers need besides the shared
+// convolution / resampling kernels: GroupNorm coefficients, Linear, spatial self-attention, a*x + b*y,
+// per-sample updates and norms.  All launch/HBM-bound; none of them is on the ACDC headline path.
+//
+// Reference semantics: torch.nn.GroupNorm(eps 1e-6) as used in models/layerspp.py:66,219 and models/ncsnpp.py:194;
+// torch.nn.Linear (models/ncsnpp.py:85-90, layerspp.py:223); AttnBlockpp.forward (models/layerspp.py:75-91);
+// the update arithmetic of ReverseDiffusionPredictor / LangevinCorrector (sde/sampling.py:200-205, 267-287).
+#include "ipdm_common.h"
+
+namespace {
+
+// one workgroup per (image, group): mean / biased variance over the group's (C/G)*HW elements (two sweeps),
+// then coef[b][c] = (mu, weight_c * rstd, bias_c) for the channels of the group
+__global__ __launch_bounds__(256) void groupnorm_coef_kernel(const float* __restrict__ x, const float* __restrict__ weight,
+                                                             const float* __restrict__ bias, float* __restrict__ coef,
+                                                             int C, int HW, int G, float eps) {
+  __shared__ double red[4];
+  const int b = blockIdx.x / G, g = blockIdx.x % G;
+  const int cpg = C / G;
+  const int64_t n = (int64_t)cpg * HW;
+  const float* p = x + ((size_t)b * C + (size_t)g * cpg) * HW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float s = 0.f;
+  for (int64_t i = tid; i < n; i += 256) s += p[i];
+  double ds = ipdm_wave_sum((double)s);
+  if (lane == 0) red[wave] = ds;
+  __syncthreads();
+  const float mean = (float)((red[0] + red[1] + red[2] + red[3]) / (double)n);
+  __syncthreads();
+  float q = 0.f;
+  for (int64_t i = tid; i < n; i += 256) {
+    float d = p[i] - mean;
+    q += d * d;
+  }
+  double dq = ipdm_wave_sum((double)q);
+  if (lane == 0) red[wave] = dq;
+  __syncthreads();
+  const float var = (float)((red[0] + red[1] + red[2] + red[3]) / (double)n);
+  const float rstd = 1.0f / sqrtf(var + eps);
+  for (int c = tid; c < cpg; c += 256) {
+    const int ch = g * cpg + c;
+    float* o = coef + ((size_t)b * C + ch) * 3;
+    o[0] = mean;
+    o[1] = (weight ? weight[ch] : 1.f) * rstd;
+    o[2] = bias ? bias[ch] : 0.f;
+  }
+}
+
+// y[b][o] = bias[o] + sum_i act(x[b][i]) * W[o][i]     (torch.nn.Linear layout), one wave per output
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                     int In, int Out, int act) {
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= B * Out) return;
+  const int b = wave / Out, o = wave % Out;
+  float s = 0.f;
+  for (int i = lane; i < In; i += 64) s += ipdm_act(x[(size_t)b * In + i], act) * W[(size_t)o * In + i];
+  s = ipdm_wave_sum(s);
+  if (lane == 0) y[(size_t)b * Out + o] = s + (bias ? bias[o] : 0.f);
+}
+
+// spatial self-attention over N = H*W positions with C channels, q/k/v/out [B][C][N]:
+//   out[:, i] = sum_j softmax_j(q[:, i] . k[:, j] * scale) v[:, j]
+// one workgroup per (image, query); N <= 1024, C <= 1024 (attention sits at 16x16 in every shipped config)
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, float* __restrict__ out, int C,
+                                                        int N, float scale) {
+  extern __shared__ float sm[];
+  float* qs = sm;            // [C]
+  float* ps = sm + C;        // [N]
+  __shared__ float red[4];
+  const int b = blockIdx.y, i = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* qb = q + (size_t)b * C * N;
+  const float* kb = k + (size_t)b * C * N;
+  const float* vb = v + (size_t)b * C * N;
+  for (int c = tid; c < C; c += 256) qs[c] = qb[(size_t)c * N + i];
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int j = tid; j < N; j += 256) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += qs[c] * kb[(size_t)c * N + j];
+    s *= scale;
+    ps[j] = s;
+    mx = fmaxf(mx, s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = tid; j < N; j += 256) {
+    float e = expf(ps[j] - mx);
+    ps[j] = e;
+    sum += e;
+  }
+  sum = ipdm_wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  for (int c = wave; c < C; c += 4) {            // one wave per channel row of v: coalesced over j
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64) s += ps[j] * vb[(size_t)c * N + j];
+    s = ipdm_wave_sum(s);
+    if (lane == 0) out[((size_t)b * C + c) * N + i] = s * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const float* x, const float* y, float* out, int64_t n, float a,
+                                                    float b) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = a * x[i] + b * y[i];
+}
+
+// out[s][:] = x[s][:] + a[s]*y[s][:] + c[s]*z[s][:]   (per-sample coefficients in device memory; z may be NULL)
+__global__ __launch_bounds__(256) void sample_axpy2_kernel(const float* x, const float* __restrict__ y,
+                                                           const float* __restrict__ z, const float* __restrict__ a,
+                                                           const float* __restrict__ c, float* out, int64_t elems) {
+  const int s = blockIdx.y;
+  const float as = a[s], cs = (z && c) ? c[s] : 0.f;
+  const size_t base = (size_t)s * elems;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < elems; i += (int64_t)gridDim.x * 256) {
+    float v = x[base + i] + as * y[base + i];
+    if (z) v += cs * z[base + i];
+    out[base + i] = v;
+  }
+}
+
+// norms[s] = ||x[s]||_2, one workgroup per sample
+__global__ __launch_bounds__(256) void sample_norm_kernel(const float* __restrict__ x, float* __restrict__ norms,
+                                                          int64_t elems) {
+  __shared__ double red[4];
+  const float* p = x + (size_t)blockIdx.x * elems;
+  float q = 0.f;
+  for (int64_t i = threadIdx.x; i < elems; i += 256) q += p[i] * p[i];
+  double dq = ipdm_wave_sum((double)q);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dq;
+  __syncthreads();
+  if (threadIdx.x == 0) norms[blockIdx.x] = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+}
+
+}  // namespace
+
+extern "C" int ipdm_groupnorm_coef_f32(const float* x, const float* weight, const float* bias, float* coef, int B, int C,
+                                       int HW, int G, float eps, void* stream) {
+  IPDM_REQUIRE(B >= 0 && C > 0 && HW > 0 && G > 0 && C % G == 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && coef);
+  hipLaunchKernelGGL(groupnorm_coef_kernel, dim3(B * G), dim3(256), 0, ipdm_stream(stream), x, weight, bias, coef, C, HW,
+                     G, eps);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_linear_f32(const float* x, const float* W, const float* bias, float* y, int B, int In, int Out,
+                               int act, void* stream) {
+  IPDM_REQUIRE(B >= 0 && In > 0 && Out > 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && W && y);
+  const int64_t waves = (int64_t)B * Out;
+  hipLaunchKernelGGL(linear_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ipdm_stream(stream), x, W, bias, y,
+                     B, In, Out, act);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int C, int N,
+                                  float scale, void* stream) {
+  IPDM_REQUIRE(B >= 0 && C > 0 && N > 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(q && k && v && out);
+  if (N > 4096 || C > 4096 || B > 65535) return IPDM_EUNSUPPORTED;
+  hipLaunchKernelGGL(attention_kernel, dim3(N, B), dim3(256), (size_t)(C + N) * sizeof(float), ipdm_stream(stream), q, k,
+                     v, out, C, N, scale);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_axpby_f32(const float* x, const float* y, float* out, int64_t n, float a, float b, void* stream) {
+  IPDM_REQUIRE(n >= 0);
+  if (n == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && y && out);
+  hipLaunchKernelGGL(axpby_kernel, dim3(ipdm_ew_grid(n, 256)), dim3(256), 0, ipdm_stream(stream), x, y, out, (long long)n,
+                     a, b);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_sample_axpy2_f32(const float* x, const float* y, const float* z, const float* a, const float* c,
+                                     float* out, int n_samples, int64_t sample_elems, void* stream) {
+  IPDM_REQUIRE(n_samples >= 0 && sample_elems >= 0 && n_samples <= 65535);
+  if (n_samples == 0 || sample_elems == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && y && a && out);
+  int gx = (int)((sample_elems + 255) / 256);
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(sample_axpy2_kernel, dim3(gx, n_samples), dim3(256), 0, ipdm_stream(stream), x, y, z, a, c, out,
+                     (long long)sample_elems);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_sample_norm_f32(const float* x, float* norms, int n_samples, int64_t sample_elems, void* stream) {
+  IPDM_REQUIRE(n_samples >= 0 && sample_elems >= 0);
+  if (n_samples == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && norms);
+  hipLaunchKernelGGL(sample_norm_kernel, dim3(n_samples), dim3(256), 0, ipdm_stream(stream), x, norms,
+                     (long long)sample_elems);
+  return ipdm_launch_status();
+}

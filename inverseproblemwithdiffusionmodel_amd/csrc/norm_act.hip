@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void add_kernel(const float* x, const float* y
 __global__ __launch_bounds__(256) void div_sigma_kernel(const float* x, const float* __restrict__ sigmas,
                                                         const int64_t* __restrict__ labels, float* out,
                                                         int64_t sample_elems) {
-  const float sg = sigmas[labels[blockIdx.y]];
+  const float sg = labels ? sigmas[labels[blockIdx.y]] : sigmas[blockIdx.y];
   const float* p = x + (size_t)blockIdx.y * sample_elems;
   float* o = out + (size_t)blockIdx.y * sample_elems;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < sample_elems; i += (int64_t)gridDim.x * 256) o[i] = p[i] / sg;
@@ -288,7 +288,7 @@ extern "C" int ipdm_div_sigma_f32(const float* x, const float* sigmas, const int
                                   int64_t sample_elems, void* stream) {
   IPDM_REQUIRE(B >= 0 && sample_elems >= 0 && B <= 65535);
   if (B == 0 || sample_elems == 0) return IPDM_OK;
-  IPDM_REQUIRE(x && sigmas && labels && out);
+  IPDM_REQUIRE(x && sigmas && out);
   int gx = (int)((sample_elems + 255) / 256);
   if (gx > 256) gx = 256;
   hipLaunchKernelGGL(div_sigma_kernel, dim3(gx, B), dim3(256), 0, ipdm_stream(stream), x, sigmas, labels, out,

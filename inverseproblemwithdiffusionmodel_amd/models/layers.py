@@ -1,0 +1,118 @@
+"""Common layers of the score_sde model zoo used by NCSN++ (mirror of the reference's ``models/layers.py``:
+get_act :29-41, variance_scaling/default_init :54-91, ddpm_conv1x1/3x3 :100-125, get_timestep_embedding :516-530,
+NIN :547-556) on the libipdm.so kernels."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ncsn.models.layers import _Act
+
+
+def get_act(config):
+    name = config.model.nonlinearity.lower()
+    if name not in ("elu", "relu", "lrelu", "swish"):
+        raise NotImplementedError('activation function does not exist!')
+    return _Act(name)
+
+
+def variance_scaling(scale, mode, distribution, in_axis=1, out_axis=0, dtype=torch.float32, device='cpu'):
+    def init(shape, dtype=dtype, device=device):
+        receptive = np.prod(shape) / shape[in_axis] / shape[out_axis]
+        fan_in, fan_out = shape[in_axis] * receptive, shape[out_axis] * receptive
+        denom = {"fan_in": fan_in, "fan_out": fan_out, "fan_avg": (fan_in + fan_out) / 2}[mode]
+        variance = scale / denom
+        if distribution == "normal":
+            return torch.randn(*shape, dtype=dtype, device=device) * np.sqrt(variance)
+        if distribution == "uniform":
+            return (torch.rand(*shape, dtype=dtype, device=device) * 2. - 1.) * np.sqrt(3 * variance)
+        raise ValueError("invalid distribution for variance scaling initializer")
+    return init
+
+
+def default_init(scale=1.):
+    scale = 1e-10 if scale == 0 else scale
+    return variance_scaling(scale, 'fan_avg', 'uniform')
+
+
+class Conv(nn.Module):
+    """stride-1 'same' convolution with nn.Conv2d's parameter names (weight [Cout,Cin,k,k], bias)"""
+
+    def __init__(self, in_planes, out_planes, kernel_size, bias=True, init_scale=1., dilation=1):
+        super().__init__()
+        self.in_planes, self.out_planes, self.kernel_size, self.dilation = in_planes, out_planes, kernel_size, dilation
+        self.weight = nn.Parameter(default_init(init_scale)((out_planes, in_planes, kernel_size, kernel_size)))
+        self.bias = nn.Parameter(torch.zeros(out_planes)) if bias else None
+        self._packed = None
+
+    def packed(self):
+        v = (self.weight._version, self.weight.data_ptr())
+        if self._packed is None or self._packed[0] != v:
+            self._packed = (v, ops.conv_pack_weight(self.weight.data))
+        return self._packed[1]
+
+    def forward(self, x, residual=None):
+        return ops.conv2d(x, self.packed(), None if self.bias is None else self.bias.data, residual=residual,
+                          dilation=self.dilation)
+
+
+def ddpm_conv1x1(in_planes, out_planes, stride=1, bias=True, init_scale=1., padding=0):
+    assert stride == 1 and padding == 0
+    return Conv(in_planes, out_planes, 1, bias=bias, init_scale=init_scale)
+
+
+def ddpm_conv3x3(in_planes, out_planes, stride=1, bias=True, dilation=1, init_scale=1., padding=1):
+    assert stride == 1 and padding == dilation
+    return Conv(in_planes, out_planes, 3, bias=bias, init_scale=init_scale, dilation=dilation)
+
+
+def get_timestep_embedding(timesteps, embedding_dim, max_positions=10000):
+    assert len(timesteps.shape) == 1
+    half_dim = embedding_dim // 2
+    emb = math.log(max_positions) / (half_dim - 1)
+    emb = torch.exp(torch.arange(half_dim, dtype=torch.float32, device=timesteps.device) * -emb)
+    emb = timesteps.float()[:, None] * emb[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
+    if embedding_dim % 2 == 1:
+        emb = torch.nn.functional.pad(emb, (0, 1), mode='constant')
+    return emb
+
+
+class NIN(nn.Module):
+    """network-in-network = 1x1 convolution with the weight stored (in_dim, num_units): exactly the packed
+    [1][Cin][Cout] layout of the MFMA convolution, so no repacking is needed"""
+
+    def __init__(self, in_dim, num_units, init_scale=0.1):
+        super().__init__()
+        self.W = nn.Parameter(default_init(scale=init_scale)((in_dim, num_units)), requires_grad=True)
+        self.b = nn.Parameter(torch.zeros(num_units), requires_grad=True)
+
+    def forward(self, x, residual=None):
+        return ops.conv2d(x, self.W.data.view(1, self.W.shape[0], self.W.shape[1]), self.b.data, residual=residual)
+
+
+class GroupNorm(nn.Module):
+    """torch.nn.GroupNorm parameters (weight, bias), evaluated as per-(b,c) coefficients + one fused
+    affine(+activation) pass"""
+
+    def __init__(self, num_groups, num_channels, eps=1e-5):
+        super().__init__()
+        self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
+        self.weight = nn.Parameter(torch.ones(num_channels))
+        self.bias = nn.Parameter(torch.zeros(num_channels))
+
+    def forward(self, x, act=ops.ACT_NONE):
+        coef = ops.groupnorm_coef(x, self.weight.data, self.bias.data, self.num_groups, self.eps)
+        return ops.affine_act(x, coef, act)
+
+
+class Linear(nn.Module):
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.weight = nn.Parameter(default_init()((out_features, in_features)))
+        self.bias = nn.Parameter(torch.zeros(out_features))
+
+    def forward(self, x, act_in=ops.ACT_NONE):
+        return ops.linear(x, self.weight.data, self.bias.data, act_in)

@@ -1,0 +1,152 @@
+"""NCSN++ layers (mirror of the reference's ``models/layerspp.py``: GaussianFourierProjection :32-41, Combine
+:44-59, AttnBlockpp :62-91, Upsample :94-127, Downsample :130-163, ResnetBlockBigGANpp :212-274)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import layers, up_or_down_sampling
+from .. import ops
+
+conv1x1 = layers.ddpm_conv1x1
+conv3x3 = layers.ddpm_conv3x3
+NIN = layers.NIN
+default_init = layers.default_init
+GroupNorm = layers.GroupNorm
+INV_SQRT2 = float(np.float32(1.0) / np.sqrt(np.float32(2.0)))
+
+
+def _groups(ch):
+    return min(ch // 4, 32)
+
+
+class GaussianFourierProjection(nn.Module):
+    """Gaussian Fourier embeddings for noise levels ((B,) -> (B, 2*embedding_size); host-sized math)"""
+
+    def __init__(self, embedding_size=256, scale=1.0):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(embedding_size) * scale, requires_grad=False)
+
+    def forward(self, x):
+        x_proj = x[:, None] * self.W[None, :] * 2 * np.pi
+        return torch.cat([torch.sin(x_proj), torch.cos(x_proj)], dim=-1)
+
+
+class Combine(nn.Module):
+    """Combine information from skip connections."""
+
+    def __init__(self, dim1, dim2, method='cat'):
+        super().__init__()
+        self.Conv_0 = conv1x1(dim1, dim2)
+        self.method = method
+
+    def forward(self, x, y):
+        if self.method == 'sum':
+            return self.Conv_0(x, residual=y)
+        if self.method == 'cat':
+            return torch.cat([self.Conv_0(x), y], dim=1)
+        raise ValueError(f'Method {self.method} not recognized.')
+
+
+def _skip(x, h, rescale):
+    return ops.axpby(x, h, INV_SQRT2, INV_SQRT2) if rescale else ops.add(x, h)
+
+
+class AttnBlockpp(nn.Module):
+    """Channel-wise self-attention block. Modified from DDPM."""
+
+    def __init__(self, channels, skip_rescale=False, init_scale=0.):
+        super().__init__()
+        self.GroupNorm_0 = GroupNorm(num_groups=_groups(channels), num_channels=channels, eps=1e-6)
+        self.NIN_0 = NIN(channels, channels)
+        self.NIN_1 = NIN(channels, channels)
+        self.NIN_2 = NIN(channels, channels)
+        self.NIN_3 = NIN(channels, channels, init_scale=init_scale)
+        self.skip_rescale = skip_rescale
+
+    def forward(self, x):
+        C = x.shape[1]
+        h = self.GroupNorm_0(x)
+        q, k, v = self.NIN_0(h), self.NIN_1(h), self.NIN_2(h)
+        h = ops.attention(q, k, v, int(C) ** (-0.5))
+        if not self.skip_rescale:
+            return self.NIN_3(h, residual=x)
+        return _skip(x, self.NIN_3(h), True)
+
+
+class Upsample(nn.Module):
+    def __init__(self, in_ch=None, out_ch=None, with_conv=False, fir=False, fir_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        out_ch = out_ch if out_ch else in_ch
+        if not fir and with_conv:
+            self.Conv_0 = conv3x3(in_ch, out_ch)
+        elif fir and with_conv:
+            self.Conv2d_0 = up_or_down_sampling.Conv2d(in_ch, out_ch, kernel=3, up=True, resample_kernel=fir_kernel,
+                                                       use_bias=True, kernel_init=default_init())
+        self.fir, self.with_conv, self.fir_kernel, self.out_ch = fir, with_conv, fir_kernel, out_ch
+
+    def forward(self, x):
+        if not self.fir:
+            h = up_or_down_sampling.naive_upsample_2d(x, 2)              # F.interpolate(..., 'nearest')
+            return self.Conv_0(h) if self.with_conv else h
+        if not self.with_conv:
+            return up_or_down_sampling.upsample_2d(x, self.fir_kernel, factor=2)
+        return self.Conv2d_0(x)
+
+
+class Downsample(nn.Module):
+    def __init__(self, in_ch=None, out_ch=None, with_conv=False, fir=False, fir_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        out_ch = out_ch if out_ch else in_ch
+        if not fir and with_conv:
+            raise NotImplementedError("strided 3x3 Downsample (fir=False, with_conv=True) needs a stride-2 convolution")
+        if fir and with_conv:
+            self.Conv2d_0 = up_or_down_sampling.Conv2d(in_ch, out_ch, kernel=3, down=True, resample_kernel=fir_kernel,
+                                                       use_bias=True, kernel_init=default_init())
+        self.fir, self.fir_kernel, self.with_conv, self.out_ch = fir, fir_kernel, with_conv, out_ch
+
+    def forward(self, x):
+        if not self.fir:
+            return up_or_down_sampling.naive_downsample_2d(x, 2)          # F.avg_pool2d(x, 2, 2)
+        if not self.with_conv:
+            return up_or_down_sampling.downsample_2d(x, self.fir_kernel, factor=2)
+        return self.Conv2d_0(x)
+
+
+class ResnetBlockBigGANpp(nn.Module):
+    def __init__(self, act, in_ch, out_ch=None, temb_dim=None, up=False, down=False, dropout=0.1, fir=False,
+                 fir_kernel=(1, 3, 3, 1), skip_rescale=True, init_scale=0.):
+        super().__init__()
+        out_ch = out_ch if out_ch else in_ch
+        self.GroupNorm_0 = GroupNorm(num_groups=_groups(in_ch), num_channels=in_ch, eps=1e-6)
+        self.up, self.down, self.fir, self.fir_kernel = up, down, fir, fir_kernel
+        self.Conv_0 = conv3x3(in_ch, out_ch)
+        if temb_dim is not None:
+            self.Dense_0 = layers.Linear(temb_dim, out_ch)
+        self.GroupNorm_1 = GroupNorm(num_groups=_groups(out_ch), num_channels=out_ch, eps=1e-6)
+        self.Conv_1 = conv3x3(out_ch, out_ch, init_scale=init_scale)          # Dropout_0 is identity when sampling
+        if in_ch != out_ch or up or down:
+            self.Conv_2 = conv1x1(in_ch, out_ch)
+        self.skip_rescale, self.act, self.in_ch, self.out_ch = skip_rescale, act, in_ch, out_ch
+
+    def forward(self, x, temb=None):
+        code = self.act.code
+        h = self.GroupNorm_0(x, code)
+        if self.up:
+            f = (lambda t: up_or_down_sampling.upsample_2d(t, self.fir_kernel, factor=2)) if self.fir else \
+                (lambda t: up_or_down_sampling.naive_upsample_2d(t, factor=2))
+            h, x = f(h), f(x)
+        elif self.down:
+            f = (lambda t: up_or_down_sampling.downsample_2d(t, self.fir_kernel, factor=2)) if self.fir else \
+                (lambda t: up_or_down_sampling.naive_downsample_2d(t, factor=2))
+            h, x = f(h), f(x)
+        h = self.Conv_0(h)
+        if temb is not None:
+            # h += Dense_0(act(temb))[:, :, None, None]: a per-(image, channel) shift, applied as affine coefficients
+            t = self.Dense_0(temb, act_in=code)
+            shift = torch.stack([torch.zeros_like(t), torch.ones_like(t), t], dim=-1).contiguous()
+            h = ops.affine_act(h, shift, ops.ACT_NONE, out=h)
+        h = self.GroupNorm_1(h, code)
+        h = self.Conv_1(h)
+        if self.in_ch != self.out_ch or self.up or self.down:
+            x = self.Conv_2(x)
+        return _skip(x, h, self.skip_rescale)

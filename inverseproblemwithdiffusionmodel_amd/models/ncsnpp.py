@@ -1,0 +1,199 @@
+"""NCSN++ score network (mirror of the reference's ``models/ncsnpp.py:34-381``): same constructor, the same
+``all_modules`` ModuleList order (so state-dict keys ``all_modules.N.*`` line up), same forward control flow.
+BigGAN residual blocks with FIR resampling (upfirdn2d), GroupNorm+SiLU, attention, progressive input/output
+pyramids; every tensor op is a libipdm.so launch."""
+import functools
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import utils, layers, layerspp
+from .. import ops
+
+ResnetBlockBigGAN = layerspp.ResnetBlockBigGANpp
+Combine = layerspp.Combine
+conv3x3 = layerspp.conv3x3
+get_act = layers.get_act
+GroupNorm = layers.GroupNorm
+
+
+@utils.register_model(name='ncsnpp')
+class NCSNpp(nn.Module):
+    """NCSN++ model"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.act = act = get_act(config)
+        self.register_buffer('sigmas', torch.tensor(utils.get_sigmas(config)))
+        self.nf = nf = config.model.nf
+        ch_mult = config.model.ch_mult
+        self.num_res_blocks = num_res_blocks = config.model.num_res_blocks
+        self.attn_resolutions = attn_resolutions = config.model.attn_resolutions
+        dropout = config.model.dropout
+        self.num_resolutions = num_resolutions = len(ch_mult)
+        self.all_resolutions = all_resolutions = [config.data.image_size // (2 ** i) for i in range(num_resolutions)]
+        self.conditional = conditional = config.model.conditional
+        fir, fir_kernel = config.model.fir, config.model.fir_kernel
+        self.skip_rescale = skip_rescale = config.model.skip_rescale
+        self.resblock_type = resblock_type = config.model.resblock_type.lower()
+        self.progressive = progressive = config.model.progressive.lower()
+        self.progressive_input = progressive_input = config.model.progressive_input.lower()
+        self.embedding_type = embedding_type = config.model.embedding_type.lower()
+        init_scale = config.model.init_scale
+        assert progressive in ['none', 'output_skip', 'residual']
+        assert progressive_input in ['none', 'input_skip', 'residual']
+        assert embedding_type in ['fourier', 'positional']
+        if resblock_type != 'biggan' or progressive == 'residual' or progressive_input == 'residual':
+            raise NotImplementedError("only the BigGAN / output_skip / input_skip variant (every shipped VE NCSN++ "
+                                      "config) is built; 'ddpm' and 'residual' need strided / transposed convolutions")
+        combiner = functools.partial(Combine, method=config.model.progressive_combine.lower())
+
+        modules = []
+        if embedding_type == 'fourier':
+            assert config.training.continuous, "Fourier features are only used for continuous training."
+            modules.append(layerspp.GaussianFourierProjection(embedding_size=nf, scale=config.model.fourier_scale))
+            embed_dim = 2 * nf
+        else:
+            embed_dim = nf
+        if conditional:
+            modules.append(layers.Linear(embed_dim, nf * 4))
+            modules.append(layers.Linear(nf * 4, nf * 4))
+
+        AttnBlock = functools.partial(layerspp.AttnBlockpp, init_scale=init_scale, skip_rescale=skip_rescale)
+        if progressive == 'output_skip':
+            self.pyramid_upsample = layerspp.Upsample(fir=fir, fir_kernel=fir_kernel, with_conv=False)
+        if progressive_input == 'input_skip':
+            self.pyramid_downsample = layerspp.Downsample(fir=fir, fir_kernel=fir_kernel, with_conv=False)
+        ResnetBlock = functools.partial(ResnetBlockBigGAN, act=act, dropout=dropout, fir=fir, fir_kernel=fir_kernel,
+                                        init_scale=init_scale, skip_rescale=skip_rescale, temb_dim=nf * 4)
+
+        channels = config.data.num_channels
+        input_pyramid_ch = channels
+        modules.append(conv3x3(channels, nf))
+        hs_c = [nf]
+        in_ch = nf
+        for i_level in range(num_resolutions):
+            for i_block in range(num_res_blocks):
+                out_ch = nf * ch_mult[i_level]
+                modules.append(ResnetBlock(in_ch=in_ch, out_ch=out_ch))
+                in_ch = out_ch
+                if all_resolutions[i_level] in attn_resolutions:
+                    modules.append(AttnBlock(channels=in_ch))
+                hs_c.append(in_ch)
+            if i_level != num_resolutions - 1:
+                modules.append(ResnetBlock(down=True, in_ch=in_ch))
+                if progressive_input == 'input_skip':
+                    modules.append(combiner(dim1=input_pyramid_ch, dim2=in_ch))
+                    if config.model.progressive_combine.lower() == 'cat':
+                        in_ch *= 2
+                hs_c.append(in_ch)
+
+        in_ch = hs_c[-1]
+        modules.append(ResnetBlock(in_ch=in_ch))
+        modules.append(AttnBlock(channels=in_ch))
+        modules.append(ResnetBlock(in_ch=in_ch))
+
+        for i_level in reversed(range(num_resolutions)):
+            for i_block in range(num_res_blocks + 1):
+                out_ch = nf * ch_mult[i_level]
+                modules.append(ResnetBlock(in_ch=in_ch + hs_c.pop(), out_ch=out_ch))
+                in_ch = out_ch
+            if all_resolutions[i_level] in attn_resolutions:
+                modules.append(AttnBlock(channels=in_ch))
+            if progressive == 'output_skip':
+                modules.append(GroupNorm(num_groups=min(in_ch // 4, 32), num_channels=in_ch, eps=1e-6))
+                modules.append(conv3x3(in_ch, channels, bias=True, init_scale=init_scale))
+            if i_level != 0:
+                modules.append(ResnetBlock(in_ch=in_ch, up=True))
+        assert not hs_c
+        if progressive != 'output_skip':
+            modules.append(GroupNorm(num_groups=min(in_ch // 4, 32), num_channels=in_ch, eps=1e-6))
+            modules.append(conv3x3(in_ch, channels, init_scale=init_scale))
+        self.all_modules = nn.ModuleList(modules)
+
+    def forward(self, x, time_cond):
+        if not x.is_cuda:
+            raise RuntimeError("NCSNpp: expected GPU tensors (no CPU fallback in this build)")
+        modules = self.all_modules
+        code = self.act.code
+        m_idx = 0
+        x = x.contiguous().float()
+        if self.embedding_type == 'fourier':
+            used_sigmas = time_cond
+            temb = modules[m_idx](torch.log(used_sigmas))
+            m_idx += 1
+        else:
+            timesteps = time_cond
+            used_sigmas = self.sigmas[time_cond.long()]
+            temb = layers.get_timestep_embedding(timesteps, self.nf)
+        if self.conditional:
+            temb = modules[m_idx](temb.float().contiguous())
+            m_idx += 1
+            temb = modules[m_idx](temb, act_in=code)
+            m_idx += 1
+        else:
+            temb = None
+        if not self.config.data.centered:
+            x = ops.scale_shift(x, 2.0, -1.0)
+
+        input_pyramid = x if self.progressive_input != 'none' else None
+        hs = [modules[m_idx](x)]
+        m_idx += 1
+        for i_level in range(self.num_resolutions):
+            for i_block in range(self.num_res_blocks):
+                h = modules[m_idx](hs[-1], temb)
+                m_idx += 1
+                if h.shape[-1] in self.attn_resolutions:
+                    h = modules[m_idx](h)
+                    m_idx += 1
+                hs.append(h)
+            if i_level != self.num_resolutions - 1:
+                h = modules[m_idx](hs[-1], temb)
+                m_idx += 1
+                if self.progressive_input == 'input_skip':
+                    input_pyramid = self.pyramid_downsample(input_pyramid)
+                    h = modules[m_idx](input_pyramid, h)
+                    m_idx += 1
+                hs.append(h)
+
+        h = hs[-1]
+        h = modules[m_idx](h, temb)
+        m_idx += 1
+        h = modules[m_idx](h)
+        m_idx += 1
+        h = modules[m_idx](h, temb)
+        m_idx += 1
+
+        pyramid = None
+        for i_level in reversed(range(self.num_resolutions)):
+            for i_block in range(self.num_res_blocks + 1):
+                h = modules[m_idx](torch.cat([h, hs.pop()], dim=1), temb)
+                m_idx += 1
+            if h.shape[-1] in self.attn_resolutions:
+                h = modules[m_idx](h)
+                m_idx += 1
+            if self.progressive == 'output_skip':
+                pyramid_h = modules[m_idx](h, code)                   # act(GroupNorm(h))
+                m_idx += 1
+                if pyramid is None:
+                    pyramid = modules[m_idx](pyramid_h)
+                else:
+                    pyramid = modules[m_idx](pyramid_h, residual=self.pyramid_upsample(pyramid))
+                m_idx += 1
+            if i_level != 0:
+                h = modules[m_idx](h, temb)
+                m_idx += 1
+        assert not hs
+        if self.progressive == 'output_skip':
+            h = pyramid
+        else:
+            h = modules[m_idx](h, code)
+            m_idx += 1
+            h = modules[m_idx](h)
+            m_idx += 1
+        assert m_idx == len(modules)
+        if self.config.model.scale_by_sigma:
+            h = ops.div_sigma(h, used_sigmas.float().contiguous())
+        return h

@@ -1,0 +1,94 @@
+"""FIR up/down-sampling wrappers (mirror of the reference's ``models/up_or_down_sampling.py``: Conv2d :23-56,
+naive_* :59-68, upsample_conv_2d :72-141, conv_downsample_2d :144-178, _setup_kernel :181-188, upsample_2d
+:195-224, downsample_2d :227-257) on the gfx950 upfirdn2d kernel."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..op import upfirdn2d
+
+
+def _setup_kernel(k):
+    k = np.asarray(k, dtype=np.float32)
+    if k.ndim == 1:
+        k = np.outer(k, k)
+    k /= np.sum(k)
+    assert k.ndim == 2 and k.shape[0] == k.shape[1]
+    return k
+
+
+_KERNEL_CACHE = {}
+
+
+def _fir(k, scale, device):
+    key = (tuple(np.asarray(k, dtype=np.float32).ravel().tolist()), float(scale), str(device))
+    if key not in _KERNEL_CACHE:
+        _KERNEL_CACHE[key] = torch.tensor(_setup_kernel(k) * scale, device=device)
+    return _KERNEL_CACHE[key]
+
+
+def upsample_2d(x, k=None, factor=2, gain=1):
+    """zero-insert by `factor` and low-pass with `k` (normalised, times gain * factor^2)"""
+    assert isinstance(factor, int) and factor >= 1
+    k = [1] * factor if k is None else k
+    fir = _fir(k, gain * (factor ** 2), x.device)
+    p = fir.shape[0] - factor
+    return upfirdn2d(x, fir, up=factor, pad=((p + 1) // 2 + factor - 1, p // 2))
+
+
+def downsample_2d(x, k=None, factor=2, gain=1):
+    """low-pass with `k` (normalised, times gain) and keep every `factor`-th sample"""
+    assert isinstance(factor, int) and factor >= 1
+    k = [1] * factor if k is None else k
+    fir = _fir(k, gain, x.device)
+    p = fir.shape[0] - factor
+    return upfirdn2d(x, fir, down=factor, pad=((p + 1) // 2, p // 2))
+
+
+def naive_upsample_2d(x, factor=2):
+    """nearest-neighbour repeat == upfirdn2d with a box filter of ones"""
+    return upsample_2d(x, [1] * factor, factor=factor)
+
+
+def naive_downsample_2d(x, factor=2):
+    """block mean == upfirdn2d with a normalised box filter"""
+    if factor == 2:
+        return ops.meanpool2(x)
+    return downsample_2d(x, [1] * factor, factor=factor)
+
+
+def upsample_conv_2d(x, w, k=None, factor=2, gain=1):
+    raise NotImplementedError("upsample_conv_2d raises in the reference itself (negative-step slice, "
+                              "models/up_or_down_sampling.py:126); no shipped config reaches it")
+
+
+def conv_downsample_2d(x, w, k=None, factor=2, gain=1):
+    raise NotImplementedError("conv_downsample_2d needs a stride-2 convolution; only reached with resblock_type='ddpm' "
+                              "or progressive*='residual', which no shipped VE config uses")
+
+
+class Conv2d(nn.Module):
+    """Conv2d layer with optional FIR up/down-sampling (StyleGAN2); plain stride-1 branch implemented."""
+
+    def __init__(self, in_ch, out_ch, kernel, up=False, down=False, resample_kernel=(1, 3, 3, 1), use_bias=True,
+                 kernel_init=None):
+        super().__init__()
+        assert not (up and down)
+        assert kernel >= 1 and kernel % 2 == 1
+        self.weight = nn.Parameter(torch.zeros(out_ch, in_ch, kernel, kernel))
+        if kernel_init is not None:
+            self.weight.data = kernel_init(self.weight.data.shape)
+        if use_bias:
+            self.bias = nn.Parameter(torch.zeros(out_ch))
+        self.up, self.down, self.resample_kernel, self.kernel, self.use_bias = up, down, resample_kernel, kernel, use_bias
+        self._packed = None
+
+    def forward(self, x):
+        if self.up:
+            return upsample_conv_2d(x, self.weight, k=self.resample_kernel)
+        if self.down:
+            return conv_downsample_2d(x, self.weight, k=self.resample_kernel)
+        if self._packed is None or self._packed[0] != self.weight._version:
+            self._packed = (self.weight._version, ops.conv_pack_weight(self.weight.data))
+        return ops.conv2d(x, self._packed[1], self.bias.data if self.use_bias else None)

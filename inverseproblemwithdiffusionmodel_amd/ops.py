@@ -201,9 +201,11 @@ def add(x, y, out=None):
     return out
 
 
-def div_sigma(x, sigmas, labels, out=None):
+def div_sigma(x, sigmas, labels=None, out=None):
+    """x[b] / sigmas[labels[b]]  (labels None: x[b] / sigmas[b])"""
     x = _gpu(x, torch.float32, "x")
-    labels = _gpu(labels, torch.int64, "labels")
+    labels = None if labels is None else _gpu(labels, torch.int64, "labels")
+    sigmas = _gpu(sigmas, torch.float32, "sigmas")
     out = torch.empty_like(x) if out is None else out
     B = x.shape[0]
     call("ipdm_div_sigma_f32", _ptr(x), _ptr(sigmas), _ptr(labels), _ptr(out), B, x.numel() // max(B, 1), _stream())
@@ -235,6 +237,62 @@ def bilinear(x, size, out=None, accumulate=False, act=ACT_NONE):
         accumulate = False
     call("ipdm_bilinear_f32", _ptr(x), _ptr(out), B * C, H, W, oh, ow, int(bool(accumulate)), act, _stream())
     return out
+
+
+# ---- NCSN++ / predictor-corrector extras --------------------------------------------------------
+def groupnorm_coef(x, weight, bias, groups, eps=1e-6):
+    x = _gpu(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    coef = torch.empty((B, C, 3), dtype=torch.float32, device=x.device)
+    call("ipdm_groupnorm_coef_f32", _ptr(x), _ptr(weight), _ptr(bias), _ptr(coef), B, C, H * W, groups, float(eps),
+         _stream())
+    return coef
+
+
+def linear(x, weight, bias=None, act_in=ACT_NONE):
+    x = _gpu(x, torch.float32, "x")
+    B, In = x.shape
+    Out = weight.shape[0]
+    y = torch.empty((B, Out), dtype=torch.float32, device=x.device)
+    call("ipdm_linear_f32", _ptr(x), _ptr(weight), _ptr(bias), _ptr(y), B, In, Out, act_in, _stream())
+    return y
+
+
+def attention(q, k, v, scale):
+    q, k, v = (_gpu(t, torch.float32, n) for t, n in ((q, "q"), (k, "k"), (v, "v")))
+    B, C, H, W = q.shape
+    out = torch.empty_like(q)
+    call("ipdm_attention_f32", _ptr(q), _ptr(k), _ptr(v), _ptr(out), B, C, H * W, float(scale), _stream())
+    return out
+
+
+def axpby(x, y, a, b, out=None):
+    x, y = _gpu(x, torch.float32, "x"), _gpu(y, torch.float32, "y")
+    if x.shape != y.shape:
+        raise ValueError(f"ipdm axpby: shapes differ {tuple(x.shape)} vs {tuple(y.shape)}")
+    out = torch.empty_like(x) if out is None else out
+    call("ipdm_axpby_f32", _ptr(x), _ptr(y), _ptr(out), x.numel(), float(a), float(b), _stream())
+    return out
+
+
+def sample_axpy2(x, y, a, z=None, c=None, out=None):
+    """x + a[:,None]*y (+ c[:,None]*z): per-sample float32 device vectors a, c"""
+    x = _gpu(x, torch.float32, "x")
+    n = x.shape[0]
+    out = torch.empty_like(x) if out is None else out
+    a = _gpu(a.to(torch.float32), torch.float32, "a")
+    c = None if c is None else _gpu(c.to(torch.float32), torch.float32, "c")
+    call("ipdm_sample_axpy2_f32", _ptr(x), _ptr(y), _ptr(z), _ptr(a), _ptr(c), _ptr(out), n,
+         x.numel() // max(n, 1), _stream())
+    return out
+
+
+def sample_norm(x):
+    x = _gpu(x, torch.float32, "x")
+    n = x.shape[0]
+    norms = torch.empty(n, dtype=torch.float32, device=x.device)
+    call("ipdm_sample_norm_f32", _ptr(x), _ptr(norms), n, x.numel() // max(n, 1), _stream())
+    return norms
 
 
 # ---- convolution ------------------------------------------------------------------------------

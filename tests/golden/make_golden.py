@@ -22,6 +22,9 @@ Fixture groups (names follow SURVEY.md 8c):
   g09_upfirdn    upfirdn2d_native / upsample_2d / downsample_2d
   g10_biasact    CPU fused_leaky_relu
   g11_temporal   reshape_temporal_dim, FiniteDiff
+  g13_pc         one 20-step VE predictor-corrector run on the tiny NCSN++ + every predictor/corrector update
+                 function for VE / VP / subVP SDEs with an analytic score, noise recorded
+  g14_ncsnpp     tiny NCSN++ (BigGAN blocks, FIR resampling, attention, progressive I/O) forward with its weights
   g15_fullnet    full-size NCSNv2Deepest (ngf=128, 128x128) forward on synthetic weights
                  produced by inverseproblemwithdiffusionmodel_amd.synthetic.synth_state_dict (weights NOT stored)
 """
@@ -464,6 +467,92 @@ def g11_temporal():
     save("g11_temporal", **out)
 
 
+class _CfgDict(dict):
+    """stand-in for ml_collections.ConfigDict (absent in this image): attribute access on a dict"""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def tiny_ncsnpp_config():
+    c = _CfgDict()
+    c.training = _CfgDict(continuous=True, sde="vesde")
+    c.sampling = _CfgDict(n_steps_each=1, noise_removal=True, probability_flow=False, snr=0.16, method="pc",
+                          predictor="reverse_diffusion", corrector="langevin")
+    c.data = _CfgDict(image_size=32, centered=False, num_channels=3)
+    c.model = _CfgDict(name="ncsnpp", sigma_max=50.0, sigma_min=0.01, num_scales=20, beta_min=0.1, beta_max=20.,
+                       dropout=0., embedding_type="fourier", scale_by_sigma=True, ema_rate=0.999,
+                       normalization="GroupNorm", nonlinearity="swish", nf=8, ch_mult=(1, 2, 2), num_res_blocks=1,
+                       attn_resolutions=(8,), resamp_with_conv=True, conditional=True, fir=True,
+                       fir_kernel=[1, 3, 3, 1], skip_rescale=True, resblock_type="biggan", progressive="output_skip",
+                       progressive_input="input_skip", progressive_combine="sum", attention_type="ddpm",
+                       init_scale=0., fourier_scale=16, conv_size=3)
+    c.device = torch.device("cpu")
+    return c
+
+
+def g13_g14_score_sde():
+    """g14: tiny NCSN++ forward.  g13: a 20-step VE predictor-corrector run on it with the noise recorded."""
+    ref_ncsnpp = importlib.import_module("InverseProblemWithDiffusionModel.models.ncsnpp")
+    ref_sde_lib = importlib.import_module("InverseProblemWithDiffusionModel.sde.sde_lib")
+    ref_sampling = importlib.import_module("InverseProblemWithDiffusionModel.sde.sampling")
+    cfg = tiny_ncsnpp_config()
+    torch.manual_seed(14)
+    net = ref_ncsnpp.NCSNpp(cfg).eval()
+    for p_ in net.parameters():             # init_scale = 0 leaves whole branches at 1e-10: make every path count
+        if p_.requires_grad:
+            p_.data = 0.15 * torch.randn_like(p_)
+    out = {}
+    out.update(_sd(net, "pp"))
+    g = torch.Generator().manual_seed(140)
+    x = torch.rand(2, 3, 32, 32, generator=g)
+    sig = torch.tensor([0.7, 12.0])
+    with torch.no_grad():
+        out["pp_x"], out["pp_sigma"], out["pp_y"] = npy(x), npy(sig), npy(net(x, sig))
+    out["pp_n_modules"] = np.array(len(net.all_modules))
+    save("g14_ncsnpp", **out)
+
+    out = {}
+    sde = ref_sde_lib.VESDE(sigma_min=0.01, sigma_max=50.0, N=20)
+    tape = _NoiseTape(130)
+    x0 = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(131)) * 50.0
+    real_randn_like = torch.randn_like
+    torch.randn_like = tape
+    orig_prior = sde.prior_sampling
+    sde.prior_sampling = lambda shape: x0.clone()
+    try:
+        fn = ref_sampling.get_sampling_fn(cfg, sde, (2, 3, 32, 32), lambda v: v, 1e-5)
+        with torch.no_grad():
+            samples, nfe = fn(net)
+    finally:
+        torch.randn_like = real_randn_like
+        sde.prior_sampling = orig_prior
+    out["x0"], out["noise"], out["samples"], out["nfe"] = npy(x0), np.stack(tape.tape), npy(samples), np.array(nfe)
+    # single update functions with an analytic score, several SDEs
+    score = lambda x_, t_: -x_ / (1.0 + t_[:, None, None, None])
+    t = torch.tensor([0.9, 0.3])
+    xs = torch.randn(2, 1, 8, 8, generator=torch.Generator().manual_seed(132))
+    out["upd_x"], out["upd_t"] = npy(xs), npy(t)
+    for name, s_ in [("ve", ref_sde_lib.VESDE(0.01, 50.0, 100)), ("vp", ref_sde_lib.VPSDE(0.1, 20, 100)),
+                     ("subvp", ref_sde_lib.subVPSDE(0.1, 20, 100))]:
+        tape = _NoiseTape(133)
+        torch.randn_like = tape
+        try:
+            for pname in ["euler_maruyama", "reverse_diffusion"] + (["ancestral_sampling"] if name != "subvp" else []):
+                a, b = ref_sampling.get_predictor(pname)(s_, score, False).update_fn(xs, t)
+                out[f"{name}_{pname}_x"], out[f"{name}_{pname}_mean"] = npy(a), npy(b)
+            # (the reference's correctors raise for subVPSDE: it has no `.alphas`, sde/sampling.py:274)
+            for cname in (["langevin", "ald"] if name != "subvp" else []):
+                a, b = ref_sampling.get_corrector(cname)(s_, score, 0.16, 2).update_fn(xs, t)
+                out[f"{name}_{cname}_x"], out[f"{name}_{cname}_mean"] = npy(a), npy(b)
+        finally:
+            torch.randn_like = real_randn_like
+        out[f"{name}_noise"] = np.stack(tape.tape)
+        mean, std = s_.marginal_prob(xs, t)
+        out[f"{name}_marginal_mean"], out[f"{name}_marginal_std"] = npy(mean), npy(std)
+        out[f"{name}_prior_logp"] = npy(s_.prior_logp(xs))
+    save("g13_pc", **out)
+
+
 def g15_fullnet():
     """Full-size ACDC score net on the synthetic weights the benchmark uses."""
     from inverseproblemwithdiffusionmodel_amd.synthetic import synth_state_dict
@@ -496,5 +585,7 @@ if __name__ == "__main__":
     if which is None or "g07" in which or "g08" in which:
         net, cfg = g07_layers()
         g08_ald(net, cfg)
+    if which is None or "g13" in which or "g14" in which:
+        g13_g14_score_sde()
     if which is None or "g15" in which:
         g15_fullnet()
