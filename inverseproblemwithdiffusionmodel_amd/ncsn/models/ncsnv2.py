@@ -50,7 +50,8 @@ class _NCSNv2Base(nn.Module):
 
     def _end(self, output, x, y):
         output = self.end_conv(self.normalizer(output, self.act.code))
-        return ops.div_sigma(output, self.sigmas, y.to(torch.int64))
+        sig = self.sigmas if self.sigmas.dtype == torch.float32 else self.sigmas.to(torch.float32)
+        return ops.div_sigma(output, sig, y.to(torch.int64))
 
     @staticmethod
     def _refine(block, pairs, shape, want_act=True):
