@@ -195,6 +195,21 @@ int ipdm_conv2d_f32(const float* x, const float* wt, const float* bias, const fl
                     const float* residual, float* out, float* out_act, int act_out,
                     int B, int Cin, int Cout, int H, int W, int k, int dilation, int pool2, void* stream);
 
+/* 3-D variant for the temporal prior (reference: nn.Conv3d(k=3, padding=dilation, dilation) call sites in
+ * ncsn/models/layers3d.py and ncsn/models/ncsn3d.py:137,141): x [B][Cin][D][H][W], weights packed by
+ * ipdm_conv_pack_weight_f32(k = 27) to [27][Cin][Cout] (k == 1: [1][Cin][Cout]).  Each depth slice is an
+ * (H x W) image of the 2-D kernel; the three depth taps are three more passes over the K loop. */
+int ipdm_conv3d_f32(const float* x, const float* wt, const float* bias, const float* coef, int act,
+                    const float* residual, float* out, float* out_act, int act_out,
+                    int B, int Cin, int Cout, int D, int H, int W, int k, int dilation, void* stream);
+
+/* MaxPool3d(kernel 5, stride 1, padding 2) on [planes][D][H][W] (volumes up to 8192 voxels) */
+int ipdm_maxpool3d5_f32(const float* x, float* y, int planes, int D, int H, int W, void* stream);
+/* tap gather for the temporal (1,1,4)/stride-2 convolutions of NCSN3DShallow: x [planes][S][T_in] ->
+ * out [planes][4][S][T_out]; mode 0 = strided conv (T_out = T_in/2), mode 1 = transposed conv (T_out = 2*T_in).
+ * A 1x1 ipdm_conv2d_f32 over the 4*C gathered channels then IS the temporal convolution. */
+int ipdm_temporal_taps_f32(const float* x, float* out, int planes, int S, int T_in, int T_out, int mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

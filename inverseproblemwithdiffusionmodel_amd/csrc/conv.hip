@@ -42,7 +42,7 @@ int forced_cfg() {
 // (8 rows x 16, LDS patch sized for dilation <= 4).  Measured on MI355X at B = 28 (scripts/bench_conv.py).
 int dispatch_conv(const ConvArgs& a, int ks, hipStream_t s) {
   const int f = forced_cfg();       // tuning aid: IPDM_CONV_CFG=<id> forces one tile configuration
-  const int64_t px = (int64_t)a.B * a.H * a.W;
+  const int64_t px = (int64_t)a.B * a.D * a.H * a.W;
   if (a.W <= 16) {
     if (f == 10) return conv_cfg_64x128s(a, ks, s);
     if (f == 11) return conv_cfg_128x128s(a, ks, s);
@@ -73,10 +73,12 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
 }  // namespace
 
 extern "C" int ipdm_conv_pack_weight_f32(const float* w, float* wt, int Cout, int Cin, int k, void* stream) {
-  IPDM_REQUIRE(w && wt && Cout > 0 && Cin > 0 && (k == 1 || k == 3));
-  const int64_t total = (int64_t)Cout * Cin * k * k;
+  IPDM_REQUIRE(w && wt && Cout > 0 && Cin > 0 && (k == 1 || k == 3 || k == 27));
+  // k = 1 / 3: 2-D kernels [Cout][Cin][k][k]; k = 27: a 3x3x3 kernel [Cout][Cin][3][3][3] (taps flattened z, y, x)
+  const int kk = k == 27 ? 27 : k * k;
+  const int64_t total = (int64_t)Cout * Cin * kk;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, ipdm_stream(stream), w, wt, Cout,
-                     Cin, k * k);
+                     Cin, kk);
   return ipdm_launch_status();
 }
 
@@ -91,6 +93,22 @@ extern "C" int ipdm_conv2d_f32(const float* x, const float* wt, const float* bia
   ConvArgs a;
   a.x = x; a.wt = wt; a.bias = bias; a.coef = coef; a.residual = residual; a.out = out; a.out_act = out_act; a.act_out = act_out;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = k == 3 ? dilation : 1; a.act = act;
+  a.D = 1; a.kd = 1;
+  a.tiles_x = a.tiles_y = a.co_tiles = 0;
+  return dispatch_conv(a, k, ipdm_stream(stream));
+}
+
+extern "C" int ipdm_conv3d_f32(const float* x, const float* wt, const float* bias, const float* coef, int act,
+                               const float* residual, float* out, float* out_act, int act_out, int B, int Cin, int Cout,
+                               int D, int H, int W, int k, int dilation, void* stream) {
+  IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0 && (k == 1 || k == 3) && dilation >= 1);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && wt && (out || out_act) && x != out && x != out_act);
+  if (k == 3 && dilation > 4) return IPDM_EUNSUPPORTED;
+  ConvArgs a;
+  a.x = x; a.wt = wt; a.bias = bias; a.coef = coef; a.residual = residual; a.out = out; a.out_act = out_act; a.act_out = act_out;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = k == 3 ? dilation : 1; a.act = act;
+  a.D = D; a.kd = k;
   a.tiles_x = a.tiles_y = a.co_tiles = 0;
   return dispatch_conv(a, k, ipdm_stream(stream));
 }

@@ -30,6 +30,7 @@ struct ConvArgs {
   float* out_act;  // act_out(result) (may be NULL)
   int act_out;
   int B, Cin, Cout, H, W, dil, act;
+  int D, kd;       // depth slices per volume (1 = plain 2-D) and depth taps (1 or 3): 3-D convolution as extra K chunks
   int tiles_x, tiles_y, co_tiles;
 };
 
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(ConvArgs a) {
   const int tx = t % a.tiles_x;
   t /= a.tiles_x;
   const int ty = t % a.tiles_y;
-  const int b = t / a.tiles_y;
+  const int bz = t / a.tiles_y;               // (volume, depth slice) pair; D == 1: the image index
+  const int b = bz / a.D, z = bz - b * a.D;
   const int co0 = co_tile * C::CO_T;
   const int y0 = ty * C::PH, x0 = tx * PW;
   const int d = KS == 3 ? a.dil : 0;          // halo actually used (<= DMAX)
@@ -107,6 +109,16 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(ConvArgs a) {
   const int h = lane >> 5, j = lane & 31;
   const int wco = wave / WPX, wpx = wave % WPX;
   const int HW = a.H * a.W;
+  const size_t cs = (size_t)a.D * HW;          // channel stride of x / out ([B][C][D][H][W])
+
+  // depth taps whose input slice exists (3-D only): each one contributes n_cc more K chunks
+  const int n_cc = (a.Cin + KC - 1) / KC;
+  int kz_list[3] = {0, 0, 0};
+  int n_kz = 0;
+  for (int kz = 0; kz < a.kd; ++kz) {
+    const int zi = z + (kz - a.kd / 2) * a.dil;
+    if (zi >= 0 && zi < a.D) kz_list[n_kz++] = kz;
+  }
 
   // ---- per-lane LDS read offsets (floats, relative to a stage base) ----
   const int a_base = h * C::CO_T + wco * NCT * 32 + j;
@@ -160,8 +172,12 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(ConvArgs a) {
   float preg[C::P_POS][KC];
   float cfreg[KC][3];        // InstanceNorm++ (mu, scale, shift) of the chunk's channels (wave-uniform -> SGPRs)
 
-  auto load_chunk = [&](int c0) {
-    const float* wb = a.wt + (size_t)c0 * a.Cout + co0;
+  auto load_chunk = [&](int ch) {
+    const int kzi = ch / n_cc;
+    const int c0 = (ch - kzi * n_cc) * KC;
+    const int kz = kzi == 0 ? kz_list[0] : (kzi == 1 ? kz_list[1] : kz_list[2]);
+    const int zi = z + (kz - a.kd / 2) * a.dil;
+    const float* wb = a.wt + ((size_t)kz * C::TAPS * a.Cin + c0) * a.Cout + co0;
 #pragma unroll
     for (int i = 0; i < C::W_VEC; ++i) {
       if constexpr (FAST) {
@@ -189,21 +205,22 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(ConvArgs a) {
         cfreg[kc][2] = cf[kc * 3 + 2];
       }
     }
-    const float* xb = a.x + ((size_t)b * a.Cin + c0) * HW;
+    const float* xb = a.x + (((size_t)b * a.Cin + c0) * a.D + zi) * HW;
 #pragma unroll
     for (int i = 0; i < C::P_POS; ++i) {
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
         if constexpr (FAST) {
-          preg[i][kc] = xb[(size_t)kc * HW + p_gofs[i]];
+          preg[i][kc] = xb[(size_t)kc * cs + p_gofs[i]];
         } else {
           float v = 0.f;
-          if (p_valid[i] && c0 + kc < a.Cin) v = xb[(size_t)kc * HW + p_gofs[i]];
+          if (p_valid[i] && c0 + kc < a.Cin) v = xb[(size_t)kc * cs + p_gofs[i]];
           preg[i][kc] = v;
         }
       }
     }
   };
+  auto chunk_c0 = [&](int ch) { return (ch % n_cc) * KC; };
 
   // one LDS-store piece of the chunk held in (wreg, preg) into stage `st`; the piece index is a type
   auto store_piece = [&](float* st, int c0, auto qc) {
@@ -283,15 +300,15 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(ConvArgs a) {
     });
   };
 
-  const int n_chunks = (a.Cin + KC - 1) / KC;
+  const int n_chunks = n_cc * n_kz;            // n_kz >= 1: the centre depth tap always exists
   load_chunk(0);
   static_for<C::PIECES>([&](auto qc) { store_piece(lds, 0, qc); });
   __syncthreads();
   for (int ch = 0; ch + 1 < n_chunks; ++ch) {
     float* cur = lds + (ch & 1) * C::BUF_ELEMS;
     float* nxt = lds + ((ch + 1) & 1) * C::BUF_ELEMS;
-    load_chunk((ch + 1) * KC);
-    compute(cur, nxt, (ch + 1) * KC, std::true_type{});
+    load_chunk(ch + 1);
+    compute(cur, nxt, chunk_c0(ch + 1), std::true_type{});
     __syncthreads();
   }
   compute(lds + ((n_chunks - 1) & 1) * C::BUF_ELEMS, nullptr, 0, std::false_type{});
@@ -310,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + (wco * NCT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (FAST || co < a.Cout) {
-          const size_t o = ((size_t)b * a.Cout + co) * HW + (size_t)gy * a.W + gx;
+          const size_t o = (((size_t)b * a.Cout + co) * a.D + z) * HW + (size_t)gy * a.W + gx;
           float v = acc[m][n][r];
           if (a.bias) v += a.bias[co];
           if (a.residual) v += a.residual[o];
@@ -328,7 +345,7 @@ int launch_conv(ConvArgs a, hipStream_t s) {
   a.tiles_x = (a.W + PW - 1) / PW;
   a.tiles_y = (a.H + C::PH - 1) / C::PH;
   a.co_tiles = (a.Cout + C::CO_T - 1) / C::CO_T;
-  const int64_t nblk = (int64_t)a.B * a.tiles_x * a.tiles_y * a.co_tiles;
+  const int64_t nblk = (int64_t)a.B * a.D * a.tiles_x * a.tiles_y * a.co_tiles;
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
   auto kern = conv_mfma_kernel<NCT, NPT, WCO, WPX, PW, DMAX, KC, KS, FAST, ACT, NORM>;
   static bool attr_set = false;                 // per instantiation; first set by an eager (non-captured) call

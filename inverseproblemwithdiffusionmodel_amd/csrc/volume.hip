@@ -1,0 +1,97 @@
+// 3-D helpers of the temporal prior (NCSN3DShallow, 8 x 8 x T volumes): 5x5x5 max-pool and the tap gather that
+// turns the strided / transposed temporal convolutions into 1x1 convolutions for the MFMA kernel.  HBM-bound.
+//
+// Reference semantics: nn.MaxPool3d(kernel_size=5, stride=1, padding=2) (CRPBlock of ncsn/models/layers3d.py);
+// nn.Conv3d(k=(1,1,4), stride=(1,1,2), padding=(0,0,1)) and nn.ConvTranspose3d(same) (ncsn/models/ncsn3d.py:176-177).
+#include "ipdm_common.h"
+
+namespace {
+
+// one workgroup per (b, c) volume, separable max over the three axes through two LDS images
+__global__ __launch_bounds__(256) void maxpool3d5_kernel(const float* __restrict__ x, float* __restrict__ y, int D, int H,
+                                                         int W) {
+  extern __shared__ float sm[];
+  const int n = D * H * W;
+  float* a = sm;
+  float* b = sm + n;
+  const float* p = x + (size_t)blockIdx.x * n;
+  for (int i = threadIdx.x; i < n; i += 256) a[i] = p[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {           // along W
+    const int w = i % W, base = i - w;
+    float m = a[i];
+    for (int o = -2; o <= 2; ++o) {
+      const int ww = w + o;
+      if (ww >= 0 && ww < W) m = fmaxf(m, a[base + ww]);
+    }
+    b[i] = m;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {           // along H
+    const int h = (i / W) % H;
+    float m = b[i];
+    for (int o = -2; o <= 2; ++o) {
+      const int hh = h + o;
+      if (hh >= 0 && hh < H) m = fmaxf(m, b[i + o * W]);
+    }
+    a[i] = m;
+  }
+  __syncthreads();
+  float* q = y + (size_t)blockIdx.x * n;
+  for (int i = threadIdx.x; i < n; i += 256) {           // along D
+    const int d = i / (H * W);
+    float m = a[i];
+    for (int o = -2; o <= 2; ++o) {
+      const int dd = d + o;
+      if (dd >= 0 && dd < D) m = fmaxf(m, a[i + o * H * W]);
+    }
+    q[i] = m;
+  }
+}
+
+// x [planes][S][T_in] -> out [planes][4][S][T_out]
+//   mode 0 (stride-2 conv, pad 1):        out[p][k][s][t] = x[p][s][2t - 1 + k]          T_out = T_in / 2
+//   mode 1 (stride-2 transposed, pad 1):  out[p][k][s][t] = xup[t + 1 - k], xup[u] = x[p][s][u/2] for even u
+__global__ __launch_bounds__(256) void temporal_taps_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                            int64_t total, int S, int T_in, int T_out, int mode) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int t = (int)(i % T_out);
+    int64_t r = i / T_out;
+    const int s = (int)(r % S);
+    r /= S;
+    const int k = (int)(r % 4);
+    const int64_t p = r / 4;
+    float v = 0.f;
+    if (mode == 0) {
+      const int ti = 2 * t - 1 + k;
+      if (ti >= 0 && ti < T_in) v = x[(p * S + s) * T_in + ti];
+    } else {
+      const int u = t + 1 - k;
+      if (u >= 0 && (u & 1) == 0 && (u >> 1) < T_in) v = x[(p * S + s) * T_in + (u >> 1)];
+    }
+    out[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int ipdm_maxpool3d5_f32(const float* x, float* y, int planes, int D, int H, int W, void* stream) {
+  IPDM_REQUIRE(planes >= 0 && D > 0 && H > 0 && W > 0);
+  if (planes == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && y && x != y);
+  const size_t lds = (size_t)2 * D * H * W * sizeof(float);
+  if (lds > 64 * 1024) return IPDM_EUNSUPPORTED;
+  hipLaunchKernelGGL(maxpool3d5_kernel, dim3(planes), dim3(256), lds, ipdm_stream(stream), x, y, D, H, W);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_temporal_taps_f32(const float* x, float* out, int planes, int S, int T_in, int T_out, int mode,
+                                      void* stream) {
+  IPDM_REQUIRE(planes >= 0 && S > 0 && T_in > 0 && T_out > 0 && (mode == 0 || mode == 1));
+  if (planes == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && out && x != out);
+  const int64_t total = (int64_t)planes * 4 * S * T_out;
+  hipLaunchKernelGGL(temporal_taps_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, ipdm_stream(stream), x, out,
+                     (long long)total, S, T_in, T_out, mode);
+  return ipdm_launch_status();
+}

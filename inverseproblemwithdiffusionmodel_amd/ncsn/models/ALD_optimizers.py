@@ -30,7 +30,8 @@ import torch
 from ... import ops
 from .proximal_op import Proximal, L2Penalty, Constrained, SingleCoil  # noqa: F401
 from ..linear_transforms.undersampling_fourier import SENSE
-from ...helpers.utils import data_transform
+from ...helpers.utils import data_transform, reshape_temporal_dim
+from ..linear_transforms.finite_diff import FiniteDiff
 
 SCHED_DTYPE = np.dtype([("step", "<f4"), ("noise_scale", "<f4"), ("coef", "<f4"), ("sigma", "<f4"),
                         ("step_id", "<i8")])
@@ -240,3 +241,130 @@ class ALDInvSegProximalRealImag(ALDOptimizer):
         x = torch.complex(x_mod_real, x_mod_imag)
         x = self.proximal(x, self.measurement.to(x.device), kwargs["alpha"] * kwargs["lr_scaled"], 1.)
         return torch.real(x).contiguous(), torch.imag(x).contiguous()
+
+
+class ALD2DTime(ALDOptimizer):
+    """2D+time sampler (mirror of the reference's ALD2DTime, ALD_optimizers.py:330-581): per iteration a spatial
+    Langevin step with the 2-D prior on all B*T frames, a temporal step (3-D prior on 8x8xT patches, or temporal
+    TV), and the SENSE L2Penalty proximal on every frame.
+
+    x_mod_shape: (B, T, C, H, W); measurement: (num_sens, B, T, C, H, W).
+    Extra optional call kwargs: noise_fn(like) (injected noise; default Philox), seed, verbose, n_levels/start_level.
+    The reference's `_screenshot` PNG dumps are no-ops here."""
+
+    def __init__(self, proximal: Proximal, scorenet_T, sigmas_T, *args, **kwargs):
+        super(ALD2DTime, self).__init__(*args, **kwargs)
+        self.proximal = proximal
+        self.scorenet_T = scorenet_T
+        self.sigmas_T_orig = sigmas_T
+        n = int((self.sigmas <= sigmas_T[0]).sum())
+        self.sigmas_T = torch.ones_like(self.sigmas) * (-1)
+        # F.interpolate(..., mode="nearest") of the temporal schedule onto the tail of the spatial one (:342-345)
+        idx = torch.floor(torch.arange(n, dtype=torch.float32) * (len(sigmas_T) / n)).long().clamp_(max=len(sigmas_T) - 1)
+        self.sigmas_T[-n:] = sigmas_T.to(self.sigmas.device)[idx.to(sigmas_T.device)].to(self.sigmas.device)
+        self.scorenet_T.sigmas = self.sigmas_T
+        self.win_size = int(np.sqrt(self.scorenet_T.config.data.channels))
+        self.finite_diff = None
+        self.if_print = False
+        self.print_args = {}
+        self._it = 0
+
+    def _noise(self, like, plane, kwargs):
+        fn = kwargs.get("noise_fn")
+        if fn is not None:
+            return fn(like).to(like.device)
+        return ops.philox_normal(tuple(like.shape), like.device, seed=kwargs.get("seed", 0), step_id=self._it,
+                                 plane=plane)
+
+    @torch.no_grad()
+    def __call__(self, **kwargs):
+        """kwargs: save_dir, lr_scaled, mode_T in [tv, diffusion1d, none, diffusion1d-only, tv-only], lamda_T,
+        if_random_shift"""
+        mode_T = kwargs.get("mode_T", "diffusion1d")
+        if_skip_spatial = False
+        if mode_T in ["diffusion1d-only", "tv-only"]:
+            self.sigmas_T = self.sigmas_T_orig
+            self.scorenet_T.sigmas = self.sigmas_T_orig
+            self.sigmas = self.sigmas_T_orig
+            if_skip_spatial = True
+        self.preprocessing_steps(**kwargs)
+        x_mod = self.init_x_mod()
+        L = self.sigmas.shape[0]
+        lv0 = kwargs.get("start_level", 0)
+        lv1 = L if kwargs.get("n_levels") is None else min(L, lv0 + kwargs["n_levels"])
+        self._steps, self._noise_scales = step_schedule(self.sigmas, self.params["step_lr"])
+        sT = self.sigmas_T.detach().to("cpu", torch.float32)
+        self._steps_T = self.params["step_lr"] * (sT / sT[-1]) ** 2
+        self._it = lv0 * self.params["n_steps_each"] * 4
+        for c in range(lv0, lv1):
+            if kwargs.get("verbose") and c % max(L // 10, 1) == 0:
+                print(f"current: {c + 1}/{L}")
+            for s in range(self.params["n_steps_each"]):
+                x_mod = self.spatial_step(x_mod, c, if_skip_spatial, kwargs)
+                x_mod = self.temporal_step(x_mod, c, mode_T, kwargs.get("lamda_T", 1.),
+                                           kwargs.get("if_random_shift", False), kwargs)
+                x_mod = self.proximal_step(x_mod, self.params["step_lr"], kwargs["lr_scaled"])
+        return [x_mod.to("cpu")]
+
+    def init_x_mod(self):
+        num_sens, B, T, C, H, W = self.measurement.shape
+        measurement = self.measurement.to(self.device).reshape(num_sens, -1, C, H, W)
+        return self.linear_tfm.conj_op(measurement).reshape(B, T, C, H, W)
+
+    def _langevin_pair(self, x_re, x_im, net, labels, step, noise_scale, kwargs):
+        """both planes through `net` as one batch, then the in-place Langevin kernel"""
+        n = x_re.shape[0]
+        x = torch.cat([x_re, x_im], dim=0).contiguous()
+        grad = net(x, torch.cat([labels, labels]))
+        nz = torch.cat([self._noise(x_re, 0, kwargs), self._noise(x_im, 1, kwargs)], dim=0)
+        self._it += 1
+        ops.langevin_step(x, grad.contiguous(), float(step), float(noise_scale), noise=nz)
+        return x[:n], x[n:]
+
+    def spatial_step(self, x_mod, c, if_skip_spatial, kwargs=None):
+        kwargs = kwargs or {}
+        if if_skip_spatial:
+            return x_mod
+        B, T, C, H, W = x_mod.shape
+        x = x_mod.reshape(-1, C, H, W)
+        labels = torch.full((x.shape[0],), c, dtype=torch.long, device=x.device)
+        re, im = self._langevin_pair(x.real.contiguous().float(), x.imag.contiguous().float(), self.scorenet, labels,
+                                     self._steps[c], self._noise_scales[c], kwargs)
+        return torch.complex(re, im).reshape(B, T, C, H, W)
+
+    def temporal_step(self, x_mod, c, mode_T, lamda_T, if_random_shift, kwargs=None):
+        kwargs = kwargs or {}
+        if "tv" in mode_T:
+            if self.finite_diff is None:
+                self.finite_diff = FiniteDiff(dims=1)
+            re = x_mod.real + self.finite_diff.log_lh_grad(x_mod.real, lamda=lamda_T)
+            im = x_mod.imag + self.finite_diff.log_lh_grad(x_mod.imag, lamda=lamda_T)
+            return torch.complex(re, im)
+        if "diffusion1d" in mode_T:
+            if float(self.sigmas_T[c]) == -1:
+                return x_mod
+            B, T, C, H, W = x_mod.shape
+            x = x_mod.permute(0, 2, 1, 3, 4).reshape(-1, T, H, W)              # (BC, T, H, W)
+            if if_random_shift:
+                shifts_np = np.random.randint(0, self.win_size, (2,))            # host RNG, shared by the batch (:472)
+                x = torch.roll(x, shifts=tuple(shifts_np.tolist()), dims=(-2, -1))
+            x = reshape_temporal_dim(x, self.win_size, self.win_size, "forward")   # (B', kx*ky, T)
+            labels = torch.full((x.shape[0],), c, dtype=torch.long, device=x.device)
+            step = self._steps_T[c] * lamda_T
+            re, im = self._langevin_pair(x.real.contiguous().float(), x.imag.contiguous().float(), self.scorenet_T,
+                                         labels, step, torch.sqrt(step * 2), kwargs)
+            x = reshape_temporal_dim(torch.complex(re, im), self.win_size, self.win_size, "backward", img_size=(H, W))
+            if if_random_shift:
+                x = torch.roll(x, shifts=tuple((-shifts_np).tolist()), dims=(-2, -1))
+            return x.reshape(B, C, T, H, W).permute(0, 2, 1, 3, 4)
+        return x_mod
+
+    def proximal_step(self, x_mod, alpha, lr_scaled):
+        B, T, C, H, W = x_mod.shape
+        num_sens = self.measurement.shape[0]
+        measurement = self.measurement.to(x_mod.device).reshape(num_sens, -1, *self.measurement.shape[3:])
+        x = self.proximal(x_mod.reshape(-1, C, H, W).contiguous(), measurement.contiguous(), alpha * lr_scaled, 1.)
+        return x.reshape(B, T, C, H, W)
+
+    def _screenshot(self, x_mod, print_args: dict):
+        return None

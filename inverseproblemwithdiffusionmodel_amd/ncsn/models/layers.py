@@ -51,13 +51,14 @@ class Conv2d(nn.Module):
     """stride-1 'same' convolution, kernel 1 or 3, optional dilation; weight in the reference's layout
     [Cout, Cin, k, k] (what checkpoints carry), repacked once to [k*k, Cin, Cout] for the MFMA kernel."""
 
-    def __init__(self, in_planes, out_planes, kernel_size=3, dilation=1, bias=True):
+    def __init__(self, in_planes, out_planes, kernel_size=3, dilation=1, bias=True, ndim=2):
         super().__init__()
-        assert kernel_size in (1, 3)
+        assert kernel_size in (1, 3) and ndim in (2, 3)
         self.in_planes, self.out_planes, self.kernel_size, self.dilation = in_planes, out_planes, kernel_size, dilation
-        self.weight = nn.Parameter(torch.empty(out_planes, in_planes, kernel_size, kernel_size))
+        self.ndim = ndim
+        self.weight = nn.Parameter(torch.empty(out_planes, in_planes, *([kernel_size] * ndim)))
         self.bias = nn.Parameter(torch.empty(out_planes)) if bias else None
-        bound = 1.0 / (in_planes * kernel_size * kernel_size) ** 0.5
+        bound = 1.0 / (in_planes * kernel_size ** ndim) ** 0.5
         nn.init.uniform_(self.weight, -bound, bound)
         if bias:
             nn.init.uniform_(self.bias, -bound, bound)
@@ -72,30 +73,38 @@ class Conv2d(nn.Module):
         return self._packed
 
     def forward(self, x, coef=None, act=ops.ACT_NONE, residual=None, out=None, act_out=ops.ACT_NONE, raw=True):
-        return ops.conv2d(x, self.packed(), None if self.bias is None else self.bias.data, coef, act, residual,
-                          self.dilation, out=out, act_out=act_out, raw=raw)
+        bias = None if self.bias is None else self.bias.data
+        if self.ndim == 3:
+            return ops.conv3d(x, self.packed(), bias, coef, act, residual, self.dilation, act_out=act_out, raw=raw)
+        return ops.conv2d(x, self.packed(), bias, coef, act, residual, self.dilation, out=out, act_out=act_out, raw=raw)
 
 
-def conv1x1(in_planes, out_planes, stride=1, bias=True, spec_norm=False):
+def conv1x1(in_planes, out_planes, stride=1, bias=True, spec_norm=False, ndim=2):
     assert stride == 1 and not spec_norm
-    return Conv2d(in_planes, out_planes, 1, bias=bias)
+    return Conv2d(in_planes, out_planes, 1, bias=bias, ndim=ndim)
 
 
-def conv3x3(in_planes, out_planes, stride=1, bias=True, spec_norm=False):
+def conv3x3(in_planes, out_planes, stride=1, bias=True, spec_norm=False, ndim=2):
     assert stride == 1 and not spec_norm
-    return Conv2d(in_planes, out_planes, 3, bias=bias)
+    return Conv2d(in_planes, out_planes, 3, bias=bias, ndim=ndim)
 
 
-def dilated_conv3x3(in_planes, out_planes, dilation, bias=True, spec_norm=False):
+def dilated_conv3x3(in_planes, out_planes, dilation, bias=True, spec_norm=False, ndim=2):
     assert not spec_norm
-    return Conv2d(in_planes, out_planes, 3, dilation=dilation, bias=bias)
+    return Conv2d(in_planes, out_planes, 3, dilation=dilation, bias=bias, ndim=ndim)
+
+
+def _maxpool(x):
+    return ops.maxpool3d5(x) if x.dim() == 5 else ops.maxpool5(x)
 
 
 class ConvMeanPool(nn.Module):
-    def __init__(self, input_dim, output_dim, kernel_size=3, biases=True, adjust_padding=False, spec_norm=False):
+    def __init__(self, input_dim, output_dim, kernel_size=3, biases=True, adjust_padding=False, spec_norm=False, ndim=2):
         super().__init__()
         if adjust_padding or spec_norm:
             raise NotImplementedError("adjust_padding / spec_norm are unused by every shipped config")
+        if ndim != 2:
+            raise NotImplementedError("the 8-way 3-D ConvMeanPool is unused by NCSN3DShallow (all its stages are dilated)")
         self.conv = Conv2d(input_dim, output_dim, kernel_size, bias=biases)
 
     def forward(self, inputs):
@@ -103,11 +112,11 @@ class ConvMeanPool(nn.Module):
 
 
 class CRPBlock(nn.Module):
-    def __init__(self, features, n_stages, act=None, maxpool=True, spec_norm=False):
+    def __init__(self, features, n_stages, act=None, maxpool=True, spec_norm=False, ndim=2):
         super().__init__()
         if not maxpool:
             raise NotImplementedError("average-pool CRP is unused by every shipped config")
-        self.convs = nn.ModuleList([conv3x3(features, features, bias=False, spec_norm=spec_norm)
+        self.convs = nn.ModuleList([conv3x3(features, features, bias=False, spec_norm=spec_norm, ndim=ndim)
                                     for _ in range(n_stages)])
         self.n_stages = n_stages
         self.act = act
@@ -119,7 +128,7 @@ class CRPBlock(nn.Module):
         x = x_act if x_act is not None else ops.act(x, code)
         path, out_act = x, None
         for i in range(self.n_stages):
-            pooled = ops.maxpool5(path)
+            pooled = _maxpool(path)
             if i == self.n_stages - 1:                       # x = conv(pool(path)) + x in one launch
                 if want_act:
                     x, out_act = self.convs[i](pooled, residual=x, act_out=code)
@@ -132,12 +141,12 @@ class CRPBlock(nn.Module):
 
 
 class RCUBlock(nn.Module):
-    def __init__(self, features, n_blocks, n_stages, act=None, spec_norm=False):
+    def __init__(self, features, n_blocks, n_stages, act=None, spec_norm=False, ndim=2):
         super().__init__()
         for i in range(n_blocks):
             for j in range(n_stages):
                 setattr(self, '{}_{}_conv'.format(i + 1, j + 1), conv3x3(features, features, bias=False,
-                                                                         spec_norm=spec_norm))
+                                                                         spec_norm=spec_norm, ndim=ndim))
         self.stride = 1
         self.n_blocks = n_blocks
         self.n_stages = n_stages
@@ -162,10 +171,10 @@ class RCUBlock(nn.Module):
 
 
 class MSFBlock(nn.Module):
-    def __init__(self, in_planes, features, spec_norm=False):
+    def __init__(self, in_planes, features, spec_norm=False, ndim=2):
         super().__init__()
         assert isinstance(in_planes, (list, tuple))
-        self.convs = nn.ModuleList([conv3x3(p, features, bias=True, spec_norm=spec_norm) for p in in_planes])
+        self.convs = nn.ModuleList([conv3x3(p, features, bias=True, spec_norm=spec_norm, ndim=ndim) for p in in_planes])
         self.features = features
 
     def forward(self, xs, shape, act_out=ops.ACT_NONE):
@@ -181,22 +190,24 @@ class MSFBlock(nn.Module):
                 else:
                     sums = conv(xs[i], residual=sums)
             else:
+                if xs[i].dim() == 5:
+                    raise NotImplementedError("trilinear resize: NCSN3DShallow only ever fuses equal-sized volumes")
                 h = conv(xs[i])
                 sums = ops.bilinear(h, shape, out=sums, accumulate=sums is not None, act=last_act)
         return sums
 
 
 class RefineBlock(nn.Module):
-    def __init__(self, in_planes, features, act=None, start=False, end=False, maxpool=True, spec_norm=False):
+    def __init__(self, in_planes, features, act=None, start=False, end=False, maxpool=True, spec_norm=False, ndim=2):
         super().__init__()
         assert isinstance(in_planes, (tuple, list))
         self.n_blocks = n_blocks = len(in_planes)
-        self.adapt_convs = nn.ModuleList([RCUBlock(in_planes[i], 2, 2, act, spec_norm=spec_norm)
+        self.adapt_convs = nn.ModuleList([RCUBlock(in_planes[i], 2, 2, act, spec_norm=spec_norm, ndim=ndim)
                                           for i in range(n_blocks)])
-        self.output_convs = RCUBlock(features, 3 if end else 1, 2, act, spec_norm=spec_norm)
+        self.output_convs = RCUBlock(features, 3 if end else 1, 2, act, spec_norm=spec_norm, ndim=ndim)
         if not start:
-            self.msf = MSFBlock(in_planes, features, spec_norm=spec_norm)
-        self.crp = CRPBlock(features, 2, act, maxpool=maxpool, spec_norm=spec_norm)
+            self.msf = MSFBlock(in_planes, features, spec_norm=spec_norm, ndim=ndim)
+        self.crp = CRPBlock(features, 2, act, maxpool=maxpool, spec_norm=spec_norm, ndim=ndim)
         self.act = act
 
     def forward(self, xs, output_shape, xs_act=None, want_act=False):
@@ -218,8 +229,12 @@ class RefineBlock(nn.Module):
 
 class ResidualBlock(nn.Module):
     def __init__(self, input_dim, output_dim, resample=None, act=None, normalization=InstanceNorm2dPlus,
-                 adjust_padding=False, dilation=None, spec_norm=False):
+                 adjust_padding=False, dilation=None, spec_norm=False, ndim=2):
         super().__init__()
+        conv3x3_ = partial(conv3x3, ndim=ndim)
+        conv1x1_ = partial(conv1x1, ndim=ndim)
+        dilated_conv3x3_ = partial(dilated_conv3x3, ndim=ndim)
+        ConvMeanPool_ = partial(ConvMeanPool, ndim=ndim)
         self.non_linearity = act
         self.input_dim = input_dim
         self.output_dim = output_dim
@@ -227,27 +242,27 @@ class ResidualBlock(nn.Module):
         self.normalization = normalization
         if resample == 'down':
             if dilation is not None:
-                self.conv1 = dilated_conv3x3(input_dim, input_dim, dilation=dilation, spec_norm=spec_norm)
+                self.conv1 = dilated_conv3x3_(input_dim, input_dim, dilation=dilation, spec_norm=spec_norm)
                 self.normalize2 = normalization(input_dim)
-                self.conv2 = dilated_conv3x3(input_dim, output_dim, dilation=dilation, spec_norm=spec_norm)
-                conv_shortcut = partial(dilated_conv3x3, dilation=dilation, spec_norm=spec_norm)
+                self.conv2 = dilated_conv3x3_(input_dim, output_dim, dilation=dilation, spec_norm=spec_norm)
+                conv_shortcut = partial(dilated_conv3x3_, dilation=dilation, spec_norm=spec_norm)
             else:
-                self.conv1 = conv3x3(input_dim, input_dim, spec_norm=spec_norm)
+                self.conv1 = conv3x3_(input_dim, input_dim, spec_norm=spec_norm)
                 self.normalize2 = normalization(input_dim)
-                self.conv2 = ConvMeanPool(input_dim, output_dim, 3, adjust_padding=adjust_padding, spec_norm=spec_norm)
-                conv_shortcut = partial(ConvMeanPool, kernel_size=1, adjust_padding=adjust_padding,
+                self.conv2 = ConvMeanPool_(input_dim, output_dim, 3, adjust_padding=adjust_padding, spec_norm=spec_norm)
+                conv_shortcut = partial(ConvMeanPool_, kernel_size=1, adjust_padding=adjust_padding,
                                         spec_norm=spec_norm)
         elif resample is None:
             if dilation is not None:
-                conv_shortcut = partial(dilated_conv3x3, dilation=dilation, spec_norm=spec_norm)
-                self.conv1 = dilated_conv3x3(input_dim, output_dim, dilation=dilation, spec_norm=spec_norm)
+                conv_shortcut = partial(dilated_conv3x3_, dilation=dilation, spec_norm=spec_norm)
+                self.conv1 = dilated_conv3x3_(input_dim, output_dim, dilation=dilation, spec_norm=spec_norm)
                 self.normalize2 = normalization(output_dim)
-                self.conv2 = dilated_conv3x3(output_dim, output_dim, dilation=dilation, spec_norm=spec_norm)
+                self.conv2 = dilated_conv3x3_(output_dim, output_dim, dilation=dilation, spec_norm=spec_norm)
             else:
-                conv_shortcut = partial(conv1x1, spec_norm=spec_norm)
-                self.conv1 = conv3x3(input_dim, output_dim, spec_norm=spec_norm)
+                conv_shortcut = partial(conv1x1_, spec_norm=spec_norm)
+                self.conv1 = conv3x3_(input_dim, output_dim, spec_norm=spec_norm)
                 self.normalize2 = normalization(output_dim)
-                self.conv2 = conv3x3(output_dim, output_dim, spec_norm=spec_norm)
+                self.conv2 = conv3x3_(output_dim, output_dim, spec_norm=spec_norm)
         else:
             raise Exception('invalid resample value')
         if output_dim != input_dim or resample is not None:

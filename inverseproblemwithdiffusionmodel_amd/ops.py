@@ -162,19 +162,20 @@ def philox_normal(shape, device, seed=0, sample_offset=0, step_id=0, plane=0):
 
 # ---- score-network glue -----------------------------------------------------------------------
 def instnorm_plus_coef(x, alpha, gamma, beta):
+    """x [B, C, *spatial] (2-D images or 3-D volumes: the statistics run over all spatial positions)"""
     x = _gpu(x, torch.float32, "x")
-    B, C, H, W = x.shape
+    B, C = x.shape[:2]
     coef = torch.empty((B, C, 3), dtype=torch.float32, device=x.device)
-    call("ipdm_instnorm_plus_coef_f32", _ptr(x), _ptr(alpha), _ptr(gamma), _ptr(beta), _ptr(coef), B, C, H * W,
-         _stream())
+    call("ipdm_instnorm_plus_coef_f32", _ptr(x), _ptr(alpha), _ptr(gamma), _ptr(beta), _ptr(coef), B, C,
+         x.numel() // max(B * C, 1), _stream())
     return coef
 
 
 def affine_act(x, coef, act=ACT_NONE, out=None):
     x = _gpu(x, torch.float32, "x")
-    B, C, H, W = x.shape
+    B, C = x.shape[:2]
     out = torch.empty_like(x) if out is None else out
-    call("ipdm_affine_act_f32", _ptr(x), _ptr(coef), _ptr(out), B, C, H * W, act, _stream())
+    call("ipdm_affine_act_f32", _ptr(x), _ptr(coef), _ptr(out), B, C, x.numel() // max(B * C, 1), act, _stream())
     return out
 
 
@@ -297,12 +298,61 @@ def sample_norm(x):
 
 # ---- convolution ------------------------------------------------------------------------------
 def conv_pack_weight(w):
+    """[Cout, Cin, k, k] -> [k*k, Cin, Cout]; a 5-D [Cout, Cin, 3, 3, 3] kernel -> [27, Cin, Cout]"""
     w = _gpu(w, torch.float32, "weight")
+    if w.dim() == 5:
+        Cout, Cin = w.shape[:2]
+        kk = w.shape[2] * w.shape[3] * w.shape[4]
+        if kk not in (1, 27):
+            raise ValueError("3-D kernels must be 1x1x1 or 3x3x3")
+        wt = torch.empty((kk, Cin, Cout), dtype=torch.float32, device=w.device)
+        call("ipdm_conv_pack_weight_f32", _ptr(w), _ptr(wt), Cout, Cin, 27 if kk == 27 else 1, _stream())
+        return wt
     Cout, Cin, k, k2 = w.shape
     assert k == k2
     wt = torch.empty((k * k, Cin, Cout), dtype=torch.float32, device=w.device)
     call("ipdm_conv_pack_weight_f32", _ptr(w), _ptr(wt), Cout, Cin, k, _stream())
     return wt
+
+
+def conv3d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, act_out=ACT_NONE, raw=True):
+    """x [B,Cin,D,H,W]; wt packed [27 or 1, Cin, Cout]; same fused input/output options as conv2d"""
+    x = _gpu(x, torch.float32, "x")
+    B, Cin, D, H, W = x.shape
+    kk, Cin_w, Cout = wt.shape
+    if Cin_w != Cin:
+        raise ValueError(f"conv3d: weight Cin {Cin_w} != input Cin {Cin}")
+    k = {1: 1, 27: 3}[kk]
+    want_act = act_out != ACT_NONE
+    out = torch.empty((B, Cout, D, H, W), dtype=torch.float32, device=x.device) if raw else None
+    out_act = torch.empty((B, Cout, D, H, W), dtype=torch.float32, device=x.device) if want_act else None
+    if CONV_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("ipdm_conv3d_f32", _ptr(x), _ptr(wt), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out), _ptr(out_act),
+         act_out, B, Cin, Cout, D, H, W, k, dilation, _stream())
+    if CONV_TRACE is not None:
+        e1.record()
+        CONV_TRACE.append(dict(B=B * D, Cin=Cin, Cout=Cout, H=H, W=W, k=k, dil=dilation, taps3d=kk, e0=e0, e1=e1))
+    return (out, out_act) if want_act else out
+
+
+def maxpool3d5(x):
+    x = _gpu(x, torch.float32, "x")
+    B, C, D, H, W = x.shape
+    out = torch.empty_like(x)
+    call("ipdm_maxpool3d5_f32", _ptr(x), _ptr(out), B * C, D, H, W, _stream())
+    return out
+
+
+def temporal_taps(x, mode):
+    """x [B,C,D,H,T] -> [B,4C,D,H,T'] (mode 0: T' = T/2 strided-conv taps; mode 1: T' = 2T transposed-conv taps)"""
+    x = _gpu(x, torch.float32, "x")
+    B, C, D, H, T = x.shape
+    T_out = T // 2 if mode == 0 else T * 2
+    out = torch.empty((B, 4 * C, D, H, T_out), dtype=torch.float32, device=x.device)
+    call("ipdm_temporal_taps_f32", _ptr(x), _ptr(out), B * C, D * H, T, T_out, mode, _stream())
+    return out
 
 
 def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, pool2=False, out=None,

@@ -22,6 +22,9 @@ Fixture groups (names follow SURVEY.md 8c):
   g09_upfirdn    upfirdn2d_native / upsample_2d / downsample_2d
   g10_biasact    CPU fused_leaky_relu
   g11_temporal   reshape_temporal_dim, FiniteDiff
+  g12_sigmas_T   ALD2DTime's temporal schedule aligned onto the spatial one (nearest interpolation, -1 head)
+  g16_ncsn3d     tiny NCSN3DShallow forward with its weights + a MaxPool3d(5,1,2) case
+  g17_ald2dtime  ALD2DTime trajectories (diffusion1d / tv / none) with the injected noise recorded
   g13_pc         one 20-step VE predictor-corrector run on the tiny NCSN++ + every predictor/corrector update
                  function for VE / VP / subVP SDEs with an analytic score, noise recorded
   g14_ncsnpp     tiny NCSN++ (BigGAN blocks, FIR resampling, attention, progressive I/O) forward with its weights
@@ -553,6 +556,86 @@ def g13_g14_score_sde():
     save("g13_pc", **out)
 
 
+def g12_g16_g17_2dtime(net2d, cfg2d):
+    """temporal prior + ALD2DTime: aligned sigma_T schedule (g12), tiny NCSN3DShallow forward (g16), 2D+time
+    sampler trajectories in modes diffusion1d / tv / none with injected noise (g17)."""
+    ref_ncsn3d = importlib.import_module("InverseProblemWithDiffusionModel.ncsn.models.ncsn3d")
+    T, H, W = 8, 32, 32
+    cfgT = tiny_config(ngf=4, num_classes=6, sigma_begin=0.5, sigma_end=0.01, channels=64, image_size=T)
+    cfgT.data.channels_3d = 1
+    torch.manual_seed(16)
+    with quiet:
+        netT = ref_ncsn3d.NCSN3DShallow(cfgT).eval()
+    for p_ in netT.parameters():
+        if p_.ndim == 1:
+            p_.data.add_(0.05 * torch.randn_like(p_))
+    out = {}
+    out.update(_sd(netT, "net3d"))
+    g = torch.Generator().manual_seed(160)
+    x = torch.rand(3, 64, T, generator=g)
+    labels = torch.tensor([0, 3, 5])
+    with torch.no_grad():
+        out["x"], out["labels"], out["y"] = npy(x), npy(labels), npy(netT(x, labels))
+    v = torch.randn(2, 3, 6, 5, 7, generator=g)
+    out["mp_x"], out["mp_y"] = npy(v), npy(torch.nn.functional.max_pool3d(v, 5, 1, 2))
+    save("g16_ncsn3d", **out)
+
+    # g12: the reference aligns sigma_T onto the spatial schedule in ALD2DTime.__init__
+    class _Dummy:
+        pass
+    out = {}
+    for name, (sp, tp) in {"cine": ((60, 0.01, 1000), (40, 0.01, 400)), "tiny": ((1.0, 0.01, 10), (0.5, 0.01, 6))}.items():
+        sig = ref_get_sigmas(tiny_config(num_classes=sp[2], sigma_begin=sp[0], sigma_end=sp[1]), "recons")
+        sigT = ref_get_sigmas(tiny_config(num_classes=tp[2], sigma_begin=tp[0], sigma_end=tp[1]), "recons")
+        d = _Dummy()
+        d.config = Namespace(data=Namespace(channels=64))
+        smp = ref_ald.ALD2DTime(None, d, sigT, (1, T, 1, H, W), None, sig, {}, None)
+        out[f"{name}_sigmas_T"] = npy(smp.sigmas_T)
+    save("g12_sigmas_T", **out)
+
+    # g17: trajectories (tiny spatial net from g07, 10 levels; tiny temporal net, 6 levels)
+    ref_ald.vis_images = lambda *a, **k: None
+    ref_ald.vis_multi_channel_signal = lambda *a, **k: None
+    orig = ref_uf.RandomUndersamplingFourier._generate_mask
+    try:
+        ref_uf.RandomUndersamplingFourier._generate_mask = t1_mask_patch(MASK_PARAMS["R8"])
+        with quiet:
+            op = ref_uf.SENSE("exp", 4, 8, 0.04, (1, H, W), seed=0)
+    finally:
+        ref_uf.RandomUndersamplingFourier._generate_mask = orig
+    g = torch.Generator().manual_seed(17)
+    B = 1
+    img = torch.complex(torch.rand(B * T, 1, H, W, generator=g), 0.3 * torch.randn(B * T, 1, H, W, generator=g))
+    meas = op(img).reshape(4, B, T, 1, H, W)
+    sigmas = ref_get_sigmas(cfg2d, "recons")
+    sigmas_T = ref_get_sigmas(cfgT, "recons")
+    out = {"measurement": npy(meas), "sigmas": npy(sigmas), "sigmas_T": npy(sigmas_T)}
+    params = dict(n_steps_each=2, step_lr=2e-5, denoise=False, final_only=True)
+    for mode, lamda_T in [("diffusion1d", 3.0), ("tv", 0.01), ("none", 1.0)]:
+        tape = _NoiseTape(170)
+        real_randn_like = torch.randn_like
+        torch.randn_like = tape
+        try:
+            with quiet:
+                netT2 = ref_ncsn3d.NCSN3DShallow(cfgT).eval()
+            netT2.load_state_dict(netT.state_dict())
+            sampler = ref_ald.ALD2DTime(ref_prox.get_proximal("L2Penalty")(op), netT2, sigmas_T, (B, T, 1, H, W), net2d,
+                                        sigmas, params, cfg2d, meas, op, device=torch.device("cpu"))
+            with quiet:
+                res = sampler(save_dir="/tmp/ipdm_oracle/out", lr_scaled=1.0e5, mode_T=mode, lamda_T=lamda_T,
+                              if_random_shift=False)[0]
+        finally:
+            torch.randn_like = real_randn_like
+            torch.set_grad_enabled(True)
+        out[f"{mode}_x"] = npy(res)
+        out[f"{mode}_lamda_T"] = np.array(lamda_T)
+        # the noise stream is NOT stored (4.7 MB): it is `torch.randn(like.shape, generator=Generator().manual_seed(170))`
+        # call after call, which the test regenerates; only its length and a checksum are kept
+        out[f"{mode}_noise_calls"] = np.array(len(tape.tape))
+        out[f"{mode}_noise_sum"] = np.array(float(sum(float(n.astype(np.float64).sum()) for n in tape.tape)))
+    save("g17_ald2dtime", **out)
+
+
 def g15_fullnet():
     """Full-size ACDC score net on the synthetic weights the benchmark uses."""
     from inverseproblemwithdiffusionmodel_amd.synthetic import synth_state_dict
@@ -582,9 +665,10 @@ if __name__ == "__main__":
     for tag, fn in steps:
         if which is None or tag in which:
             fn()
-    if which is None or "g07" in which or "g08" in which:
+    if which is None or "g07" in which or "g08" in which or "g17" in which:
         net, cfg = g07_layers()
         g08_ald(net, cfg)
+        g12_g16_g17_2dtime(net, cfg)
     if which is None or "g13" in which or "g14" in which:
         g13_g14_score_sde()
     if which is None or "g15" in which:

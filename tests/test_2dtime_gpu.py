@@ -1,0 +1,131 @@
+"""Config 4 path: temporal prior NCSN3DShallow and the 2D+time sampler ALD2DTime on the GPU against the reference's
+own outputs (tests/golden/g12_sigmas_T.npz, g16_ncsn3d.npz, g17_ald2dtime.npz)."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import state_dict_from_golden
+from oracle import metrics
+from test_scorenet_gpu import tiny_config
+
+pytestmark = pytest.mark.gpu
+
+T, H, W = 8, 32, 32
+
+
+def cfg3d():
+    c = tiny_config(ngf=4, num_classes=6, sigma_begin=0.5, sigma_end=0.01)
+    c.data.channels, c.data.channels_3d, c.data.image_size = 64, 1, T
+    return c
+
+
+@pytest.fixture(scope="module")
+def net3d(golden):
+    from inverseproblemwithdiffusionmodel_amd.ncsn.models.ncsn3d import NCSN3DShallow
+    g = golden("g16_ncsn3d")
+    m = NCSN3DShallow(cfg3d())
+    sd = state_dict_from_golden(g, "net3d")
+    assert sorted(sd) == sorted(m.state_dict())                    # the reference's keys and 5-D weight shapes
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval()
+
+
+def test_maxpool3d(golden):
+    from inverseproblemwithdiffusionmodel_amd import ops
+    g = golden("g16_ncsn3d")
+    assert torch.equal(ops.maxpool3d5(torch.from_numpy(g["mp_x"]).cuda()).cpu(), torch.from_numpy(g["mp_y"]))
+
+
+@pytest.mark.parametrize("dil,Cin,Cout,D,Hh,Ww", [(1, 8, 16, 8, 8, 24), (2, 16, 32, 8, 8, 12), (4, 32, 32, 8, 8, 24),
+                                                  (1, 1, 8, 5, 6, 7), (2, 8, 1, 4, 8, 24)])
+def test_conv3d_vs_torch(dil, Cin, Cout, D, Hh, Ww):
+    from inverseproblemwithdiffusionmodel_amd import ops
+    gen = torch.Generator().manual_seed(20)
+    x = torch.randn(3, Cin, D, Hh, Ww, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (Cin * 27) ** 0.5
+    b = torch.randn(Cout, generator=gen)
+    r = torch.randn(3, Cout, D, Hh, Ww, generator=gen)
+    want = F.conv3d(x.double(), w.double(), b.double(), padding=dil, dilation=dil) + r.double()
+    got = ops.conv3d(x.cuda(), ops.conv_pack_weight(w.cuda()), b.cuda(), residual=r.cuda(), dilation=dil)
+    assert (got.cpu().double() - want).abs().max() < 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_temporal_convs_vs_torch():
+    from inverseproblemwithdiffusionmodel_amd.ncsn.models.ncsn3d import _TemporalConv
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 8, 4, 4, 12, generator=gen)
+    down = _TemporalConv(8, 8, transposed=False)
+    up = _TemporalConv(8, 16, transposed=True)
+    want_d = F.conv3d(x, down.weight.data, down.bias.data, stride=(1, 1, 2), padding=(0, 0, 1))
+    want_u = F.conv_transpose3d(x, up.weight.data, up.bias.data, stride=(1, 1, 2), padding=(0, 0, 1))
+    assert (down.cuda()(x.cuda()).cpu() - want_d).abs().max() < 1e-5
+    assert (up.cuda()(x.cuda()).cpu() - want_u).abs().max() < 1e-5
+
+
+def test_ncsn3d_shallow_forward_golden(net3d, golden):
+    g = golden("g16_ncsn3d")
+    with torch.no_grad():
+        y = net3d(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["labels"]).cuda()).cpu().numpy()
+    ref = g["y"]
+    assert y.shape == ref.shape == (3, 64, T)
+    assert np.abs(y - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
+def _sampler(golden, net3d, mode):
+    from inverseproblemwithdiffusionmodel_amd.ncsn.models import ncsnv2, ALD_optimizers, proximal_op
+    from inverseproblemwithdiffusionmodel_amd.ncsn.linear_transforms.undersampling_fourier import SENSE
+    g7, g = golden("g07_layers"), golden("g17_ald2dtime")
+    net2d = ncsnv2.NCSNv2Deepest(tiny_config())
+    net2d.load_state_dict(state_dict_from_golden(g7, "net"), strict=True)
+    net2d = net2d.cuda().eval()
+    op = SENSE("exp", 4, 8, 0.04, (1, H, W), seed=0)
+    sigmas, sigmas_T = torch.from_numpy(g["sigmas"]).cuda(), torch.from_numpy(g["sigmas_T"]).cuda()
+    params = dict(n_steps_each=2, step_lr=2e-5, denoise=False, final_only=True)
+    meas = torch.from_numpy(g["measurement"]).cuda()
+    return g, ALD_optimizers.ALD2DTime(proximal_op.get_proximal("L2Penalty")(op), net3d, sigmas_T, (1, T, 1, H, W), net2d,
+                                       sigmas, params, tiny_config(), meas, op, device=torch.device("cuda"))
+
+
+def test_sigmas_T_alignment(golden, net3d):
+    from inverseproblemwithdiffusionmodel_amd.ncsn.models import ALD_optimizers
+    from oracle import kspace
+    g = golden("g12_sigmas_T")
+    for name, sp, tp in [("cine", (60, 0.01, 1000), (40, 0.01, 400)), ("tiny", (1.0, 0.01, 10), (0.5, 0.01, 6))]:
+        sig = torch.from_numpy(kspace.get_sigmas(*sp))
+        sigT = torch.from_numpy(kspace.get_sigmas(*tp))
+        dummy = Namespace(config=Namespace(data=Namespace(channels=64)), sigmas=None)
+        smp = ALD_optimizers.ALD2DTime(None, dummy, sigT, (1, T, 1, H, W), None, sig, {}, None, device=torch.device("cpu"))
+        assert np.array_equal(smp.sigmas_T.numpy(), g[f"{name}_sigmas_T"])          # bit-exact index logic
+    assert int((torch.from_numpy(g["cine_sigmas_T"]) == -1).sum()) == 47
+
+
+class _SeededNoise:
+    """the generator make_golden.py used: randn(like.shape) call after call from Generator().manual_seed(170)"""
+
+    def __init__(self):
+        self.g, self.calls, self.total = torch.Generator().manual_seed(170), 0, 0.0
+
+    def __call__(self, like):
+        n = torch.randn(like.shape, generator=self.g, dtype=torch.float32)
+        self.calls += 1
+        self.total += float(n.double().sum())
+        return n
+
+
+@pytest.mark.parametrize("mode", ["diffusion1d", "tv", "none"])
+def test_ald2dtime_trajectory_golden(golden, net3d, mode):
+    g, sampler = _sampler(golden, net3d, mode)
+    noise = _SeededNoise()
+    x = sampler(save_dir=None, lr_scaled=1.0e5, mode_T=mode, lamda_T=float(g[f"{mode}_lamda_T"]), if_random_shift=False,
+                noise_fn=noise)[0].numpy()
+    assert noise.calls == int(g[f"{mode}_noise_calls"])
+    assert abs(noise.total - float(g[f"{mode}_noise_sum"])) < 1e-3          # same stream as the reference run
+    ref = g[f"{mode}_x"]
+    assert x.shape == ref.shape == (1, T, 1, H, W)
+    assert metrics.nrmse(np.abs(x), np.abs(ref)) < 1e-3
+    for t in range(T):
+        assert abs(metrics.ssim(np.abs(x[0, t, 0]), np.abs(ref[0, t, 0])) - 1) < 1e-3
+    np.testing.assert_allclose(x, ref, atol=2e-3)
