@@ -1,0 +1,276 @@
+// Winograd F(2x2, 3x3) convolution on the fp32 matrix cores for the undilated 3x3 layers with wide images.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 2x2 output tile, 4x4 input tile d, 3x3 filter g
+// turns the 9-tap convolution into 16 independent channel contractions  M_p[co, tile] = sum_ci U_p[co,ci] V_p[ci,tile]
+// (p = position in the 4x4 transformed tile): 16 multiply-adds per 4 outputs instead of 36 -> 2.25x fewer MFMA
+// cycles, still exact-fp32 fma chains.  U = G g G^T is precomputed once per model ([16][Cin][Cout]).
+//
+// Workgroup = 64 output channels x 64 tiles (4 tile rows x 16 tiles = 8 x 32 output pixels) of one image;
+// 4 waves = 2 (channel halves) x 2 (tile halves); a wave keeps all 16 positions of its 32 x 32 (co x tile) block
+// in 256 accumulator registers, so the output transform A^T M A is plain per-lane register arithmetic and the
+// lane <-> tile map gives float2 (8-byte) coalesced stores.
+// Per chunk of 8 input channels: U chunk (32 KiB) global -> regs -> LDS; the 4x4 input patches go global -> regs,
+// are transformed (B^T d B, 32 adds) in the shadow of the MFMAs and land as V in LDS; two LDS stages, one barrier
+// per chunk, operand reads software-pipelined one MFMA group ahead (same scheme as conv_kernel.h).
+//
+// Used by ipdm_conv2d_f32 when: 3x3, dilation 1, Cin % 8 == 0, Cout % 64 == 0, H and W even, W >= 32, no fused
+// input normalisation/activation (the network hands activated tensors to its convolutions).
+#include "conv_kernel.h"
+
+namespace ipdm_conv {
+
+namespace {
+
+constexpr int W_KC = 8;                 // input channels per chunk
+constexpr int W_CO = 64;                // output channels per workgroup
+constexpr int W_TX = 16, W_TY = 4;      // tiles per workgroup (x, y)
+constexpr int W_TILES = W_TX * W_TY;    // 64
+constexpr int W_U_ELEMS = 16 * W_KC * W_CO;       // 8192 floats
+constexpr int W_V_ELEMS = 16 * W_KC * W_TILES;    // 8192 floats
+constexpr int W_STAGE = W_U_ELEMS + W_V_ELEMS;    // 64 KiB per stage
+constexpr size_t W_LDS_BYTES = 2 * (size_t)W_STAGE * sizeof(float);
+
+// U[p = a*4+b][ci][co] = sum_ij G[a][i] g[co][ci][i][j] G[b][j]
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout,
+                                                          int Cin) {
+  const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+  const int64_t total = (int64_t)Cout * Cin;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int co = (int)(idx % Cout), ci = (int)(idx / Cout);
+    const float* g = w + ((size_t)co * Cin + ci) * 9;
+    float t[4][3];
+    for (int a = 0; a < 4; ++a)
+      for (int j = 0; j < 3; ++j) t[a][j] = G[a][0] * g[j] + G[a][1] * g[3 + j] + G[a][2] * g[6 + j];
+    for (int a = 0; a < 4; ++a)
+      for (int b = 0; b < 4; ++b)
+        U[((size_t)(a * 4 + b) * Cin + ci) * Cout + co] = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(ConvArgs a) {
+  extern __shared__ __align__(16) float lds[];
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, slot = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int co_tile = bid % a.co_tiles;
+  int t = bid / a.co_tiles;
+  const int tx = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int ty = t % a.tiles_y;
+  const int b = t / a.tiles_y;
+  const int co0 = co_tile * W_CO;
+  const int y0 = ty * (2 * W_TY), x0 = tx * (2 * W_TX);     // output-pixel origin of the workgroup
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const int wco = wave >> 1, wtl = wave & 1;
+  const int HW = a.H * a.W;
+
+  // ---- MFMA operand read offsets inside a stage ----
+  const int a_base = h * W_CO + wco * 32 + j;                       // Us[p][kc][co]
+  const int b_base = W_U_ELEMS + h * W_TILES + wtl * 32 + j;        // Vs[p][kc][tile]
+
+  // ---- staging geometry: this thread transforms tile `mytile` for channels kc = tid/64 and 4 + tid/64 ----
+  const int mytile = tid & 63, kc_a = tid >> 6;
+  const int tyl = mytile / W_TX, txl = mytile % W_TX;
+  // 4x4 patch addresses = (clamped row offset) + (clamped column offset); padding is zero-selected after the load
+  int row_off[4], col_off[4];
+  unsigned p_valid = 0, rv = 0, cv = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int gy = y0 + 2 * tyl - 1 + e, gx = x0 + 2 * txl - 1 + e;
+    const bool oky = gy >= 0 && gy < a.H, okx = gx >= 0 && gx < a.W;
+    row_off[e] = oky ? gy * a.W : 0;
+    col_off[e] = okx ? gx : 0;
+    rv |= oky ? (1u << e) : 0u;
+    cv |= okx ? (1u << e) : 0u;
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) p_valid |= (((rv >> (e / 4)) & (cv >> (e % 4))) & 1u) << e;
+  // U chunk: float4 number v = tid + i*256 of the [16 pos][8 kc][64 co] block; consecutive i are 2 positions apart
+  const int u_gofs0 = ((tid >> 7) * a.Cin + ((tid >> 4) & 7)) * a.Cout + (tid & 15) * 4;
+  const int u_stride = 2 * a.Cin * a.Cout;
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+  float ureg[8][4];
+  float dreg[2][16];
+
+  auto load_chunk = [&](int c0) {
+    const float* ub = a.wt + (size_t)c0 * a.Cout + co0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 t4 = *reinterpret_cast<const float4*>(ub + u_gofs0 + (size_t)i * u_stride);
+      ureg[i][0] = t4.x; ureg[i][1] = t4.y; ureg[i][2] = t4.z; ureg[i][3] = t4.w;
+    }
+    // keep the (L2-resident) weight loads AHEAD of the (HBM) patch loads: vmcnt retires in issue order and the
+    // weight pieces are consumed first -- hipcc otherwise hoists the 32 patch loads in front
+    __builtin_amdgcn_sched_barrier(0);
+    const float* xa = a.x + ((size_t)b * a.Cin + c0 + kc_a) * HW;
+    const float* xb = xa + (size_t)4 * HW;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      dreg[0][e] = xa[row_off[e / 4] + col_off[e % 4]];
+      dreg[1][e] = xb[row_off[e / 4] + col_off[e % 4]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // pieces 0..7: one float4 of U each; pieces 8, 9: B^T d B of one (channel, tile) pair -> 16 LDS words
+  auto store_piece = [&](float* st, auto qc) {
+    constexpr int q = decltype(qc)::value;
+    if constexpr (q < 8) {
+      reinterpret_cast<float4*>(st)[tid + q * 256] = make_float4(ureg[q][0], ureg[q][1], ureg[q][2], ureg[q][3]);
+    } else {
+      constexpr int s = q - 8;
+      float d[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) d[e] = (p_valid >> e) & 1u ? dreg[s][e] : 0.f;
+      float tmp[16];                       // B^T d : rows (d0-d2, d1+d2, d2-d1, d1-d3)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        tmp[0 * 4 + c] = d[0 * 4 + c] - d[2 * 4 + c];
+        tmp[1 * 4 + c] = d[1 * 4 + c] + d[2 * 4 + c];
+        tmp[2 * 4 + c] = d[2 * 4 + c] - d[1 * 4 + c];
+        tmp[3 * 4 + c] = d[1 * 4 + c] - d[3 * 4 + c];
+      }
+      const int kc = s == 0 ? kc_a : kc_a + 4;
+      float* vs = st + W_U_ELEMS + kc * W_TILES + mytile;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {        // (B^T d) B : columns the same way
+        vs[(r * 4 + 0) * W_KC * W_TILES] = tmp[r * 4 + 0] - tmp[r * 4 + 2];
+        vs[(r * 4 + 1) * W_KC * W_TILES] = tmp[r * 4 + 1] + tmp[r * 4 + 2];
+        vs[(r * 4 + 2) * W_KC * W_TILES] = tmp[r * 4 + 2] - tmp[r * 4 + 1];
+        vs[(r * 4 + 3) * W_KC * W_TILES] = tmp[r * 4 + 1] - tmp[r * 4 + 3];
+      }
+    }
+  };
+
+  // group g (16 per chunk): k-step ks = g / 4 (two channels), positions 4*(g%4) .. +3
+  auto load_ops = [&](const float* cur, auto gc, float (&av)[4], float (&bv)[4]) {
+    constexpr int g = decltype(gc)::value;
+    constexpr int ks = g / 4, pg = g % 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      av[i] = cur[((pg * 4 + i) * W_KC + 2 * ks) * W_CO + a_base];
+      bv[i] = cur[((pg * 4 + i) * W_KC + 2 * ks) * W_TILES + b_base];
+    }
+  };
+  constexpr int GROUPS = 16, PIECES = 10, FIRST = GROUPS - PIECES;
+  auto compute = [&](const float* cur, float* nxt, auto store_flag) {
+    constexpr bool STORE = decltype(store_flag)::value;
+    float av[2][4], bv[2][4];
+    load_ops(cur, std::integral_constant<int, 0>{}, av[0], bv[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<GROUPS>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int pg = g % 4;
+      if constexpr (g + 1 < GROUPS) load_ops(cur, std::integral_constant<int, g + 1>{}, av[(g + 1) & 1], bv[(g + 1) & 1]);
+      constexpr bool HAS_STORE = STORE && g >= FIRST;
+      if constexpr (HAS_STORE) store_piece(nxt, std::integral_constant<int, g - FIRST>{});
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[pg * 4 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][i], bv[g & 1][i], acc[pg * 4 + i], 0, 0, 0);
+      if constexpr (g + 1 < GROUPS) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      constexpr bool IS_V = HAS_STORE && (g - FIRST) >= 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (HAS_STORE) __builtin_amdgcn_sched_group_barrier(0x006, IS_V ? 16 : 2, 0);
+      }
+      if constexpr (HAS_STORE) __builtin_amdgcn_sched_group_barrier(0x200, IS_V ? 16 : 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  const int n_chunks = a.Cin / W_KC;
+  load_chunk(0);
+  static_for<PIECES>([&](auto qc) { store_piece(lds, qc); });
+  __syncthreads();
+  for (int ch = 0; ch + 1 < n_chunks; ++ch) {
+    float* cur = lds + (ch & 1) * W_STAGE;
+    float* nxt = lds + ((ch + 1) & 1) * W_STAGE;
+    load_chunk((ch + 1) * W_KC);
+    compute(cur, nxt, std::true_type{});
+    __syncthreads();
+  }
+  compute(lds + ((n_chunks - 1) & 1) * W_STAGE, nullptr, std::false_type{});
+
+  // ---- epilogue: Y = A^T M A per lane, bias / residual / activated copy, float2 stores ----
+  const int tile = wtl * 32 + j;
+  const int oy = y0 + 2 * (tile / W_TX), ox = x0 + 2 * (tile % W_TX);
+  if (oy < a.H && ox < a.W) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      float m[16];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) m[p] = acc[p][r];
+      float tt[2][4];                         // A^T M
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        tt[0][c] = m[0 * 4 + c] + m[1 * 4 + c] + m[2 * 4 + c];
+        tt[1][c] = m[1 * 4 + c] - m[2 * 4 + c] - m[3 * 4 + c];
+      }
+      const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float y0v = tt[i][0] + tt[i][1] + tt[i][2] + bias;
+        float y1v = tt[i][1] - tt[i][2] - tt[i][3] + bias;
+        const size_t o = ((size_t)b * a.Cout + co) * HW + (size_t)(oy + i) * a.W + ox;
+        if (a.residual) {
+          const float2 rr = *reinterpret_cast<const float2*>(a.residual + o);
+          y0v += rr.x;
+          y1v += rr.y;
+        }
+        if (a.out) *reinterpret_cast<float2*>(a.out + o) = make_float2(y0v, y1v);
+        if (a.out_act) {
+          const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
+          const float e1 = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
+          *reinterpret_cast<float2*>(a.out_act + o) = make_float2(e0, e1);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool wino_ok(const ConvArgs& a, int ks) {
+  return ks == 3 && a.dil == 1 && a.D == 1 && a.Cin % W_KC == 0 && a.Cout % W_CO == 0 && a.H % 2 == 0 && a.W % 2 == 0 &&
+         a.W >= 32 && a.H >= 8 && !a.coef && a.act == IPDM_ACT_NONE;
+}
+
+// a.wt must be the Winograd-domain weights U [16][Cin][Cout] (ipdm_conv_wino_weight_f32)
+int conv_wino_launch(ConvArgs a, hipStream_t s) {
+  a.tiles_x = (a.W + 2 * W_TX - 1) / (2 * W_TX);
+  a.tiles_y = (a.H + 2 * W_TY - 1) / (2 * W_TY);
+  a.co_tiles = a.Cout / W_CO;
+  const int64_t nblk = (int64_t)a.B * a.tiles_x * a.tiles_y * a.co_tiles;
+  if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)nblk), dim3(256), W_LDS_BYTES, s, a);
+  return ipdm_launch_status();
+}
+
+int conv_wino_weights(const float* w, float* U, int Cout, int Cin, hipStream_t s) {
+  const int64_t total = (int64_t)Cout * Cin;
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, s, w, U, Cout, Cin);
+  return ipdm_launch_status();
+}
+
+}  // namespace ipdm_conv

@@ -8,6 +8,7 @@ emit the ACTIVATED copy of its result: the RCU / CRP chains (`x = act(x); x = co
 never run a separate activation pass -- blocks hand each other (raw, activated) pairs.  InstanceNorm++ +
 ELU in front of the ResidualBlock convolutions is one fused affine+activation kernel; the 5x5 max-pool,
 2x2 mean-pool and bilinear accumulate(+activation) are single kernels."""
+import os
 from functools import partial
 
 import torch
@@ -26,6 +27,10 @@ class _Act:
 
     def __call__(self, x):
         return ops.act(x, self.code)
+
+
+# Winograd F(2x2,3x3) for eligible layers (3x3, dilation 1, wide images); IPDM_WINOGRAD=0 forces the direct kernel
+USE_WINOGRAD = os.environ.get("IPDM_WINOGRAD", "1") != "0"
 
 
 def get_act(config):
@@ -64,6 +69,13 @@ class Conv2d(nn.Module):
             nn.init.uniform_(self.bias, -bound, bound)
         self._packed = None
         self._packed_version = None
+        self._wino = None
+
+    def packed_wino(self):
+        v = (self.weight._version, self.weight.data_ptr())
+        if self._wino is None or self._wino[0] != v:
+            self._wino = (v, ops.conv_wino_weight(self.weight.data))
+        return self._wino[1]
 
     def packed(self):
         v = (self.weight._version, self.weight.data_ptr())
@@ -74,6 +86,10 @@ class Conv2d(nn.Module):
 
     def forward(self, x, coef=None, act=ops.ACT_NONE, residual=None, out=None, act_out=ops.ACT_NONE, raw=True):
         bias = None if self.bias is None else self.bias.data
+        if (USE_WINOGRAD and self.ndim == 2 and self.kernel_size == 3 and self.dilation == 1 and coef is None
+                and act == ops.ACT_NONE and out is None
+                and ops.conv_wino_supported(self.in_planes, self.out_planes, x.shape[2], x.shape[3])):
+            return ops.conv2d_wino(x, self.packed_wino(), bias, residual, act_out=act_out, raw=raw)
         if self.ndim == 3:
             return ops.conv3d(x, self.packed(), bias, coef, act, residual, self.dilation, act_out=act_out, raw=raw)
         return ops.conv2d(x, self.packed(), bias, coef, act, residual, self.dilation, out=out, act_out=act_out, raw=raw)

@@ -315,6 +315,38 @@ def conv_pack_weight(w):
     return wt
 
 
+def conv_wino_weight(w):
+    """[Cout, Cin, 3, 3] -> Winograd-domain weights U = G g G^T, [16, Cin, Cout]"""
+    w = _gpu(w, torch.float32, "weight")
+    Cout, Cin = w.shape[:2]
+    U = torch.empty((16, Cin, Cout), dtype=torch.float32, device=w.device)
+    call("ipdm_conv_wino_weight_f32", _ptr(w), _ptr(U), Cout, Cin, _stream())
+    return U
+
+
+def conv_wino_supported(Cin, Cout, H, W):
+    return bool(_lib.lib.ipdm_conv2d_wino_supported(Cin, Cout, H, W))
+
+
+def conv2d_wino(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True):
+    """3x3 / dilation-1 convolution through the Winograd F(2x2,3x3) kernel (same output options as conv2d)"""
+    x = _gpu(x, torch.float32, "x")
+    B, Cin, H, W = x.shape
+    Cout = U.shape[2]
+    want_act = act_out != ACT_NONE
+    out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device) if raw else None
+    out_act = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device) if want_act else None
+    if CONV_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("ipdm_conv2d_wino_f32", _ptr(x), _ptr(U), _ptr(bias), _ptr(residual), _ptr(out), _ptr(out_act), act_out,
+         B, Cin, Cout, H, W, _stream())
+    if CONV_TRACE is not None:
+        e1.record()
+        CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=1, wino=True, e0=e0, e1=e1))
+    return (out, out_act) if want_act else out
+
+
 def conv3d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, act_out=ACT_NONE, raw=True):
     """x [B,Cin,D,H,W]; wt packed [27 or 1, Cin, Cout]; same fused input/output options as conv2d"""
     x = _gpu(x, torch.float32, "x")

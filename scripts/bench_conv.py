@@ -12,6 +12,7 @@ from inverseproblemwithdiffusionmodel_amd import ops
 B = int(os.environ.get("BENCH_B", 28))
 ONLY = os.environ.get("BENCH_ONLY")          # e.g. "0,1,2": indices into SHAPES
 NO_MIOPEN = os.environ.get("BENCH_NO_MIOPEN") == "1"
+WINO = os.environ.get("BENCH_WINO") == "1"     # Winograd F(2x2,3x3) path where eligible
 FUSED = os.environ.get("BENCH_FUSED") == "1"   # ELU + InstanceNorm++ coefficients on the input, residual on the output
 SHAPES = [  # (count per forward, Cin, Cout, H, dil)
     (18, 128, 128, 128, 1), (9, 128, 128, 64, 1), (8, 256, 256, 64, 1), (17, 256, 256, 32, 1),
@@ -42,7 +43,11 @@ for idx, (cnt, ci, co, hw, dil) in enumerate(SHAPES):
     out = torch.empty(B, co, hw, hw, device="cuda")
     flop = 2.0 * B * hw * hw * ci * co * 9
     t_m = 1e9 if NO_MIOPEN else timeit(lambda: F.conv2d(x, w, bias, padding=dil, dilation=dil))
-    if FUSED and ci > 1:
+    if WINO and dil == 1 and ops.conv_wino_supported(ci, co, hw, hw):
+        U = ops.conv_wino_weight(w)
+        t_o = timeit(lambda: ops.conv2d_wino(x, U, bias))
+        out = ops.conv2d_wino(x, U, bias)
+    elif FUSED and ci > 1:
         coef = torch.randn(B, ci, 3, device="cuda")
         res = torch.randn(B, co, hw, hw, device="cuda")
         t_o = timeit(lambda: ops.conv2d(x, wt, bias, coef, ops.ACT_ELU, res, dilation=dil, out=out))
