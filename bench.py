@@ -207,6 +207,10 @@ def main():
         engine.conv_census(prob.scorenet, x, labels)                 # warm
         reps = [engine.conv_census(prob.scorenet, x, labels) for _ in range(3)]
         flops = sum(r["flops"] for r in reps[0])
+        # Winograd F(2x2,3x3) launches execute 16 instead of 36 multiply-adds per 2x2 output tile
+        executed = sum(r["flops"] / (2.25 if r.get("wino") else 1.0) for r in reps[0])
+        n_wino = sum(1 for r in reps[0] if r.get("wino"))
+        bytes_alg = sum(4.0 * r["B"] * r["H"] * r["W"] * (r["Cin"] + r["Cout"]) for r in reps[0]) / len(reps[0])
         conv_ms = float(np.median([sum(r["ms"] for r in rep) for rep in reps]))
         log(f"conv census: {len(reps[0])} launches, {conv_ms:.2f} ms, {flops / 1e12:.3f} TFLOP per step")
         achieved = flops / (conv_ms * 1e-3) / 1e12
@@ -218,7 +222,12 @@ def main():
         out["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-            "kernel": "conv_mfma_kernel<...> (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv)",
+            "kernel": "conv_mfma_kernel<...> + conv_wino_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM / Winograd conv)",
+            "achieved_note": "algorithmic FLOPs (2*MACs of the direct convolution) / measured conv time; the Winograd "
+                             "launches execute 2.25x fewer MFMA FLOPs, see executed_*",
+            "winograd_launches": n_wino, "executed_mfma_tflops": executed / (conv_ms * 1e-3) / 1e12,
+            "executed_mfma_frac": executed / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "algorithmic_bytes_per_launch": bytes_alg,
             "launches_per_step": len(reps[0]), "avg_launch_ms": conv_ms / len(reps[0]),
             "algorithmic_flops_per_step": flops, "conv_ms_per_step": conv_ms,
             "conv_share_of_step": conv_ms / ms_per_step,

@@ -6,9 +6,9 @@
 // cycles, still exact-fp32 fma chains.  U = G g G^T is precomputed once per model ([16][Cin][Cout]).
 //
 // Workgroup = 64 output channels x 64 tiles (4 tile rows x 16 tiles = 8 x 32 output pixels) of one image;
-// 4 waves = 2 (channel halves) x 2 (tile halves); a wave keeps all 16 positions of its 32 x 32 (co x tile) block
-// in 256 accumulator registers, so the output transform A^T M A is plain per-lane register arithmetic and the
-// lane <-> tile map gives float2 (8-byte) coalesced stores.
+// 8 waves = 2 (position halves) x 2 (channel halves) x 2 (tile halves); a wave keeps 8 of the 16 positions of its
+// 32 x 32 (co x tile) block in 128 accumulator registers; the output transform A^T M A is per-lane register
+// arithmetic on each half plus one LDS hand-off, and the lane <-> tile map gives float2 (8-byte) coalesced stores.
 // Per chunk of 8 input channels: U chunk (32 KiB) global -> regs -> LDS; the 4x4 input patches go global -> regs,
 // are transformed (B^T d B, 32 adds) in the shadow of the MFMAs and land as V in LDS; two LDS stages, one barrier
 // per chunk, operand reads software-pipelined one MFMA group ahead (same scheme as conv_kernel.h).
@@ -47,7 +47,11 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256, 1) void conv_wino_kernel(ConvArgs a) {
+// 512 threads = 8 waves = 2 (position halves) x 2 (channel halves) x 2 (tile halves): two waves per SIMD, so one
+// wave's load / LDS latencies are covered by its partner's MFMAs.  Wave `ph` owns positions 8*ph .. 8*ph+7 (rows
+// 2*ph, 2*ph+1 of the 4x4 transformed tile) = 128 accumulator registers; the output transform is linear, so each
+// wave reduces its half to a partial 2x2 result and the halves meet once through LDS in the epilogue.
+__global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
   extern __shared__ __align__(16) float lds[];
   const int nblk = gridDim.x;
   int bid = blockIdx.x;
@@ -67,14 +71,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
-  const int wco = wave >> 1, wtl = wave & 1;
+  const int ph = wave >> 2, wco = (wave >> 1) & 1, wtl = wave & 1;
   const int HW = a.H * a.W;
 
-  // ---- MFMA operand read offsets inside a stage ----
-  const int a_base = h * W_CO + wco * 32 + j;                       // Us[p][kc][co]
-  const int b_base = W_U_ELEMS + h * W_TILES + wtl * 32 + j;        // Vs[p][kc][tile]
+  // ---- MFMA operand read offsets inside a stage (position offset added per group) ----
+  const int a_base = (ph * 8 * W_KC + h) * W_CO + wco * 32 + j;                    // Us[p][kc][co]
+  const int b_base = W_U_ELEMS + (ph * 8 * W_KC + h) * W_TILES + wtl * 32 + j;     // Vs[p][kc][tile]
 
-  // ---- staging geometry: this thread transforms tile `mytile` for channels kc = tid/64 and 4 + tid/64 ----
+  // ---- staging geometry: this thread transforms tile `mytile` of channel kc = tid / 64 ----
   const int mytile = tid & 63, kc_a = tid >> 6;
   const int tyl = mytile / W_TX, txl = mytile % W_TX;
   // 4x4 patch addresses = (clamped row offset) + (clamped column offset); padding is zero-selected after the load
@@ -91,49 +95,44 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(ConvArgs a) {
   }
 #pragma unroll
   for (int e = 0; e < 16; ++e) p_valid |= (((rv >> (e / 4)) & (cv >> (e % 4))) & 1u) << e;
-  // U chunk: float4 number v = tid + i*256 of the [16 pos][8 kc][64 co] block; consecutive i are 2 positions apart
+  // U chunk: float4 number v = tid + i*512 of the [16 pos][8 kc][64 co] block; consecutive i are 4 positions apart
   const int u_gofs0 = ((tid >> 7) * a.Cin + ((tid >> 4) & 7)) * a.Cout + (tid & 15) * 4;
-  const int u_stride = 2 * a.Cin * a.Cout;
+  const int u_stride = 4 * a.Cin * a.Cout;
 
-  f32x16 acc[16];
+  f32x16 acc[8];
 #pragma unroll
-  for (int p = 0; p < 16; ++p)
+  for (int p = 0; p < 8; ++p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-  float ureg[8][4];
-  float dreg[2][16];
+  float ureg[4][4];
+  float dreg[16];
 
   auto load_chunk = [&](int c0) {
     const float* ub = a.wt + (size_t)c0 * a.Cout + co0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 4; ++i) {
       const float4 t4 = *reinterpret_cast<const float4*>(ub + u_gofs0 + (size_t)i * u_stride);
       ureg[i][0] = t4.x; ureg[i][1] = t4.y; ureg[i][2] = t4.z; ureg[i][3] = t4.w;
     }
     // keep the (L2-resident) weight loads AHEAD of the (HBM) patch loads: vmcnt retires in issue order and the
-    // weight pieces are consumed first -- hipcc otherwise hoists the 32 patch loads in front
+    // weight pieces are consumed first -- hipcc otherwise hoists the patch loads in front
     __builtin_amdgcn_sched_barrier(0);
     const float* xa = a.x + ((size_t)b * a.Cin + c0 + kc_a) * HW;
-    const float* xb = xa + (size_t)4 * HW;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      dreg[0][e] = xa[row_off[e / 4] + col_off[e % 4]];
-      dreg[1][e] = xb[row_off[e / 4] + col_off[e % 4]];
-    }
+    for (int e = 0; e < 16; ++e) dreg[e] = xa[row_off[e / 4] + col_off[e % 4]];
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // pieces 0..7: one float4 of U each; pieces 8, 9: B^T d B of one (channel, tile) pair -> 16 LDS words
+  // pieces 0..3: one float4 of U each; piece 4: B^T d B of this thread's (channel, tile) pair -> 16 LDS words
   auto store_piece = [&](float* st, auto qc) {
     constexpr int q = decltype(qc)::value;
-    if constexpr (q < 8) {
-      reinterpret_cast<float4*>(st)[tid + q * 256] = make_float4(ureg[q][0], ureg[q][1], ureg[q][2], ureg[q][3]);
+    if constexpr (q < 4) {
+      reinterpret_cast<float4*>(st)[tid + q * 512] = make_float4(ureg[q][0], ureg[q][1], ureg[q][2], ureg[q][3]);
     } else {
-      constexpr int s = q - 8;
       float d[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) d[e] = (p_valid >> e) & 1u ? dreg[s][e] : 0.f;
+      for (int e = 0; e < 16; ++e) d[e] = (p_valid >> e) & 1u ? dreg[e] : 0.f;
       float tmp[16];                       // B^T d : rows (d0-d2, d1+d2, d2-d1, d1-d3)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -142,8 +141,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(ConvArgs a) {
         tmp[2 * 4 + c] = d[2 * 4 + c] - d[1 * 4 + c];
         tmp[3 * 4 + c] = d[1 * 4 + c] - d[3 * 4 + c];
       }
-      const int kc = s == 0 ? kc_a : kc_a + 4;
-      float* vs = st + W_U_ELEMS + kc * W_TILES + mytile;
+      float* vs = st + W_U_ELEMS + kc_a * W_TILES + mytile;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {        // (B^T d) B : columns the same way
         vs[(r * 4 + 0) * W_KC * W_TILES] = tmp[r * 4 + 0] - tmp[r * 4 + 2];
@@ -154,17 +152,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(ConvArgs a) {
     }
   };
 
-  // group g (16 per chunk): k-step ks = g / 4 (two channels), positions 4*(g%4) .. +3
+  // group g (8 per chunk): k-step ks = g / 2 (two channels), this wave's positions 4*(g%2) .. +3
   auto load_ops = [&](const float* cur, auto gc, float (&av)[4], float (&bv)[4]) {
     constexpr int g = decltype(gc)::value;
-    constexpr int ks = g / 4, pg = g % 4;
+    constexpr int ks = g / 2, pg = g % 2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       av[i] = cur[((pg * 4 + i) * W_KC + 2 * ks) * W_CO + a_base];
       bv[i] = cur[((pg * 4 + i) * W_KC + 2 * ks) * W_TILES + b_base];
     }
   };
-  constexpr int GROUPS = 16, PIECES = 10, FIRST = GROUPS - PIECES;
+  constexpr int GROUPS = 8, PIECES = 5, FIRST = GROUPS - PIECES;
   auto compute = [&](const float* cur, float* nxt, auto store_flag) {
     constexpr bool STORE = decltype(store_flag)::value;
     float av[2][4], bv[2][4];
@@ -172,7 +170,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     static_for<GROUPS>([&](auto gc) {
       constexpr int g = decltype(gc)::value;
-      constexpr int pg = g % 4;
+      constexpr int pg = g % 2;
       if constexpr (g + 1 < GROUPS) load_ops(cur, std::integral_constant<int, g + 1>{}, av[(g + 1) & 1], bv[(g + 1) & 1]);
       constexpr bool HAS_STORE = STORE && g >= FIRST;
       if constexpr (HAS_STORE) store_piece(nxt, std::integral_constant<int, g - FIRST>{});
@@ -180,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(ConvArgs a) {
       for (int i = 0; i < 4; ++i)
         acc[pg * 4 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][i], bv[g & 1][i], acc[pg * 4 + i], 0, 0, 0);
       if constexpr (g + 1 < GROUPS) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-      constexpr bool IS_V = HAS_STORE && (g - FIRST) >= 8;
+      constexpr bool IS_V = HAS_STORE && (g - FIRST) >= 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -204,27 +202,47 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(ConvArgs a) {
   }
   compute(lds + ((n_chunks - 1) & 1) * W_STAGE, nullptr, std::false_type{});
 
-  // ---- epilogue: Y = A^T M A per lane, bias / residual / activated copy, float2 stores ----
+  // ---- epilogue: each wave reduces its 8 positions (rows 2ph, 2ph+1 of M) to a partial Y = A^T M A, the ph = 1
+  //      wave hands its partial to the ph = 0 wave through LDS, which adds bias / residual and stores float2 ----
+  // A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]: row a of M enters tt[0] with (1,1,1,0)[a] and tt[1] with (0,1,-1,-1)[a]
+  const float c00 = ph == 0 ? 1.f : 1.f, c01 = ph == 0 ? 1.f : 0.f;     // tt[0] coefficients of rows (2ph, 2ph+1)
+  const float c10 = ph == 0 ? 0.f : -1.f, c11 = ph == 0 ? 1.f : -1.f;   // tt[1] coefficients
+  __syncthreads();                                                       // everyone is done with the stages
+  float* ex = lds + ((wco * 2 + wtl) * 16) * 4 * 64;                     // [pair][r][4][lane]
   const int tile = wtl * 32 + j;
   const int oy = y0 + 2 * (tile / W_TX), ox = x0 + 2 * (tile % W_TX);
-  if (oy < a.H && ox < a.W) {
+  float yv[16][4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float tt[2][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float m0 = acc[c][r], m1 = acc[4 + c][r];                    // rows 2ph and 2ph+1, column c
+      tt[0][c] = c00 * m0 + c01 * m1;
+      tt[1][c] = c10 * m0 + c11 * m1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      yv[r][i * 2 + 0] = tt[i][0] + tt[i][1] + tt[i][2];
+      yv[r][i * 2 + 1] = tt[i][1] - tt[i][2] - tt[i][3];
+    }
+  }
+  if (ph == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) ex[(r * 4 + v) * 64 + lane] = yv[r][v];
+  }
+  __syncthreads();
+  if (ph == 0 && oy < a.H && ox < a.W) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      float m[16];
-#pragma unroll
-      for (int p = 0; p < 16; ++p) m[p] = acc[p][r];
-      float tt[2][4];                         // A^T M
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        tt[0][c] = m[0 * 4 + c] + m[1 * 4 + c] + m[2 * 4 + c];
-        tt[1][c] = m[1 * 4 + c] - m[2 * 4 + c] - m[3 * 4 + c];
-      }
       const float bias = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        float y0v = tt[i][0] + tt[i][1] + tt[i][2] + bias;
-        float y1v = tt[i][1] - tt[i][2] - tt[i][3] + bias;
+        float y0v = yv[r][i * 2 + 0] + ex[(r * 4 + i * 2 + 0) * 64 + lane] + bias;
+        float y1v = yv[r][i * 2 + 1] + ex[(r * 4 + i * 2 + 1) * 64 + lane] + bias;
         const size_t o = ((size_t)b * a.Cout + co) * HW + (size_t)(oy + i) * a.W + ox;
         if (a.residual) {
           const float2 rr = *reinterpret_cast<const float2*>(a.residual + o);
@@ -263,7 +281,7 @@ int conv_wino_launch(ConvArgs a, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)nblk), dim3(256), W_LDS_BYTES, s, a);
+  hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)nblk), dim3(512), W_LDS_BYTES, s, a);
   return ipdm_launch_status();
 }
 
