@@ -198,11 +198,14 @@ int ipdm_conv2d_f32(const float* x, const float* wt, const float* bias, const fl
 /* Winograd F(2x2,3x3) variant of the 3x3 / dilation-1 convolution: 16 multiply-adds per 4 outputs instead of 36
  * (2.25x fewer MFMA cycles), exact-fp32 fma chains in the transformed domain.  U = G g G^T is produced once per
  * layer by ipdm_conv_wino_weight_f32 ([16][Cin][Cout]).  ipdm_conv2d_wino_supported tells whether a shape is
- * eligible (Cin % 8 == 0, Cout % 64 == 0, even H and W, W >= 32); otherwise use ipdm_conv2d_f32. */
+ * eligible (Cin % 8 == 0, Cout % 64 == 0; wide images: even H, W, dilation 1; small or dilated images: H and W
+ * divisible by 2*dilation -- a dilated convolution is run as dilation^2 interleaved undilated ones); otherwise use
+ * ipdm_conv2d_f32. */
 int ipdm_conv_wino_weight_f32(const float* w /* [Cout][Cin][3][3] */, float* U, int Cout, int Cin, void* stream);
-int ipdm_conv2d_wino_supported(int Cin, int Cout, int H, int W);
+int ipdm_conv2d_wino_supported(int Cin, int Cout, int H, int W, int dilation);
 int ipdm_conv2d_wino_f32(const float* x, const float* U, const float* bias, const float* residual, float* out,
-                         float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, void* stream);
+                         float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
+                         void* stream);
 
 /* 3-D variant for the temporal prior (reference: nn.Conv3d(k=3, padding=dilation, dilation) call sites in
  * ncsn/models/layers3d.py and ncsn/models/ncsn3d.py:137,141): x [B][Cin][D][H][W], weights packed by

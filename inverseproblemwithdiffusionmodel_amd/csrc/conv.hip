@@ -119,20 +119,21 @@ extern "C" int ipdm_conv_wino_weight_f32(const float* w, float* U, int Cout, int
   return conv_wino_weights(w, U, Cout, Cin, ipdm_stream(stream));
 }
 
-extern "C" int ipdm_conv2d_wino_supported(int Cin, int Cout, int H, int W) {
+extern "C" int ipdm_conv2d_wino_supported(int Cin, int Cout, int H, int W, int dilation) {
   ConvArgs a;
-  a.coef = nullptr; a.act = IPDM_ACT_NONE; a.dil = 1; a.D = 1; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.coef = nullptr; a.act = IPDM_ACT_NONE; a.dil = dilation; a.D = 1; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   return wino_ok(a, 3) ? 1 : 0;
 }
 
 extern "C" int ipdm_conv2d_wino_f32(const float* x, const float* U, const float* bias, const float* residual, float* out,
-                                    float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, void* stream) {
-  IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0);
+                                    float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
+                                    void* stream) {
+  IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && dilation >= 1);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && U && (out || out_act) && x != out && x != out_act);
   ConvArgs a;
   a.x = x; a.wt = U; a.bias = bias; a.coef = nullptr; a.residual = residual; a.out = out; a.out_act = out_act;
-  a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = 1; a.act = IPDM_ACT_NONE;
+  a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = dilation; a.act = IPDM_ACT_NONE;
   a.D = 1; a.kd = 1; a.tiles_x = a.tiles_y = a.co_tiles = 0;
   if (!wino_ok(a, 3)) return IPDM_EUNSUPPORTED;
   return conv_wino_launch(a, ipdm_stream(stream));

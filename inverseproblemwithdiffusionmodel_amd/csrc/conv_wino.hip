@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 // wave's load / LDS latencies are covered by its partner's MFMAs.  Wave `ph` owns positions 8*ph .. 8*ph+7 (rows
 // 2*ph, 2*ph+1 of the 4x4 transformed tile) = 128 accumulator registers; the output transform is linear, so each
 // wave reduces its half to a partial 2x2 result and the halves meet once through LDS in the epilogue.
+template <bool SMALL>
 __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
   extern __shared__ __align__(16) float lds[];
   const int nblk = gridDim.x;
@@ -66,7 +67,22 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
   const int ty = t % a.tiles_y;
   const int b = t / a.tiles_y;
   const int co0 = co_tile * W_CO;
-  const int y0 = ty * (2 * W_TY), x0 = tx * (2 * W_TX);     // output-pixel origin of the workgroup
+  const int y0 = ty * (2 * W_TY), x0 = tx * (2 * W_TX);     // output-pixel origin of the workgroup (!SMALL)
+  // SMALL: the workgroup owns 64 consecutive tiles of the image's linear tile space.  A dilation-d convolution
+  // is d*d independent undilated convolutions on the d-subsampled images (polyphase), so tile number
+  //   t = ((sy*d + sx)*THS + tyy)*TWS + txx   covers output pixels (d*(2*tyy+i) + sy, d*(2*txx+j) + sx)
+  // and reads input pixels d apart; a 16x16 image is exactly 64 tiles for d = 1, 2 and 4.
+  const int d = a.dil;
+  const int TWS = SMALL ? a.W / (2 * d) : 0, THS = SMALL ? a.H / (2 * d) : 0;
+  const int tile0 = SMALL ? tx * W_TILES : 0;               // tiles_x counts 64-tile groups, tiles_y == 1
+  auto tile_origin = [&](int tl, int& py, int& px) {        // top-left OUTPUT pixel of tile tl (SMALL)
+    const int txx = tl % TWS;
+    int r = tl / TWS;
+    const int tyy = r % THS;
+    r /= THS;
+    py = d * (2 * tyy) + r / d;
+    px = d * (2 * txx) + r % d;
+  };
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -84,10 +100,17 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
   // 4x4 patch addresses = (clamped row offset) + (clamped column offset); padding is zero-selected after the load
   int row_off[4], col_off[4];
   unsigned p_valid = 0, rv = 0, cv = 0;
+  int my_py = 0, my_px = 0;
+  bool my_tile_ok = true;
+  if constexpr (SMALL) {
+    my_tile_ok = tile0 + mytile < THS * TWS * d * d;
+    tile_origin(my_tile_ok ? tile0 + mytile : 0, my_py, my_px);
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int gy = y0 + 2 * tyl - 1 + e, gx = x0 + 2 * txl - 1 + e;
-    const bool oky = gy >= 0 && gy < a.H, okx = gx >= 0 && gx < a.W;
+    const int gy = SMALL ? my_py + d * (e - 1) : y0 + 2 * tyl - 1 + e;
+    const int gx = SMALL ? my_px + d * (e - 1) : x0 + 2 * txl - 1 + e;
+    const bool oky = my_tile_ok && gy >= 0 && gy < a.H, okx = gx >= 0 && gx < a.W;
     row_off[e] = oky ? gy * a.W : 0;
     col_off[e] = okx ? gx : 0;
     rv |= oky ? (1u << e) : 0u;
@@ -210,7 +233,12 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
   __syncthreads();                                                       // everyone is done with the stages
   float* ex = lds + ((wco * 2 + wtl) * 16) * 4 * 64;                     // [pair][r][4][lane]
   const int tile = wtl * 32 + j;
-  const int oy = y0 + 2 * (tile / W_TX), ox = x0 + 2 * (tile % W_TX);
+  int oy = y0 + 2 * (tile / W_TX), ox = x0 + 2 * (tile % W_TX);
+  bool out_ok = oy < a.H && ox < a.W;
+  if constexpr (SMALL) {
+    out_ok = tile0 + tile < THS * TWS * d * d;
+    tile_origin(out_ok ? tile0 + tile : 0, oy, ox);
+  }
   float yv[16][4];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -234,7 +262,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
       for (int v = 0; v < 4; ++v) ex[(r * 4 + v) * 64 + lane] = yv[r][v];
   }
   __syncthreads();
-  if (ph == 0 && oy < a.H && ox < a.W) {
+  if (ph == 0 && out_ok) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -243,17 +271,32 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
       for (int i = 0; i < 2; ++i) {
         float y0v = yv[r][i * 2 + 0] + ex[(r * 4 + i * 2 + 0) * 64 + lane] + bias;
         float y1v = yv[r][i * 2 + 1] + ex[(r * 4 + i * 2 + 1) * 64 + lane] + bias;
-        const size_t o = ((size_t)b * a.Cout + co) * HW + (size_t)(oy + i) * a.W + ox;
-        if (a.residual) {
-          const float2 rr = *reinterpret_cast<const float2*>(a.residual + o);
-          y0v += rr.x;
-          y1v += rr.y;
-        }
-        if (a.out) *reinterpret_cast<float2*>(a.out + o) = make_float2(y0v, y1v);
-        if (a.out_act) {
-          const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
-          const float e1 = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
-          *reinterpret_cast<float2*>(a.out_act + o) = make_float2(e0, e1);
+        const size_t o = ((size_t)b * a.Cout + co) * HW + (size_t)(oy + (SMALL ? d * i : i)) * a.W + ox;
+        if constexpr (SMALL) {                 // the two outputs of a tile row are d pixels apart
+          if (a.residual) {
+            y0v += a.residual[o];
+            y1v += a.residual[o + d];
+          }
+          if (a.out) {
+            a.out[o] = y0v;
+            a.out[o + d] = y1v;
+          }
+          if (a.out_act) {
+            a.out_act[o] = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
+            a.out_act[o + d] = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
+          }
+        } else {
+          if (a.residual) {
+            const float2 rr = *reinterpret_cast<const float2*>(a.residual + o);
+            y0v += rr.x;
+            y1v += rr.y;
+          }
+          if (a.out) *reinterpret_cast<float2*>(a.out + o) = make_float2(y0v, y1v);
+          if (a.out_act) {
+            const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
+            const float e1 = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
+            *reinterpret_cast<float2*>(a.out_act + o) = make_float2(e0, e1);
+          }
         }
       }
     }
@@ -262,26 +305,43 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
 
 }  // namespace
 
+static bool wino_small(const ConvArgs& a) {
+  // small images (or any dilation): linear tile space, needs H, W divisible by 2*dil
+  return a.W < 32 || a.dil > 1;
+}
+
 bool wino_ok(const ConvArgs& a, int ks) {
-  return ks == 3 && a.dil == 1 && a.D == 1 && a.Cin % W_KC == 0 && a.Cout % W_CO == 0 && a.H % 2 == 0 && a.W % 2 == 0 &&
-         a.W >= 32 && a.H >= 8 && !a.coef && a.act == IPDM_ACT_NONE;
+  if (!(ks == 3 && a.D == 1 && a.Cin % W_KC == 0 && a.Cout % W_CO == 0 && !a.coef && a.act == IPDM_ACT_NONE)) return false;
+  if (a.dil < 1 || a.dil > 4) return false;
+  if (wino_small(a)) return a.H % (2 * a.dil) == 0 && a.W % (2 * a.dil) == 0 && (a.H * a.W) / 4 >= 32;
+  return a.H % 2 == 0 && a.W % 2 == 0 && a.H >= 8;
 }
 
 // a.wt must be the Winograd-domain weights U [16][Cin][Cout] (ipdm_conv_wino_weight_f32)
 int conv_wino_launch(ConvArgs a, hipStream_t s) {
-  a.tiles_x = (a.W + 2 * W_TX - 1) / (2 * W_TX);
-  a.tiles_y = (a.H + 2 * W_TY - 1) / (2 * W_TY);
+  const bool small = wino_small(a);
+  if (small) {
+    a.tiles_x = ((a.H * a.W) / 4 + W_TILES - 1) / W_TILES;
+    a.tiles_y = 1;
+  } else {
+    a.tiles_x = (a.W + 2 * W_TX - 1) / (2 * W_TX);
+    a.tiles_y = (a.H + 2 * W_TY - 1) / (2 * W_TY);
+  }
   a.co_tiles = a.Cout / W_CO;
   const int64_t nblk = (int64_t)a.B * a.tiles_x * a.tiles_y * a.co_tiles;
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)nblk), dim3(512), W_LDS_BYTES, s, a);
+  if (small) hipLaunchKernelGGL(conv_wino_kernel<true>, dim3((unsigned)nblk), dim3(512), W_LDS_BYTES, s, a);
+  else hipLaunchKernelGGL(conv_wino_kernel<false>, dim3((unsigned)nblk), dim3(512), W_LDS_BYTES, s, a);
   return ipdm_launch_status();
 }
 

@@ -86,10 +86,11 @@ class Conv2d(nn.Module):
 
     def forward(self, x, coef=None, act=ops.ACT_NONE, residual=None, out=None, act_out=ops.ACT_NONE, raw=True):
         bias = None if self.bias is None else self.bias.data
-        if (USE_WINOGRAD and self.ndim == 2 and self.kernel_size == 3 and self.dilation == 1 and coef is None
-                and act == ops.ACT_NONE and out is None
-                and ops.conv_wino_supported(self.in_planes, self.out_planes, x.shape[2], x.shape[3])):
-            return ops.conv2d_wino(x, self.packed_wino(), bias, residual, act_out=act_out, raw=raw)
+        if (USE_WINOGRAD and self.ndim == 2 and self.kernel_size == 3 and coef is None and act == ops.ACT_NONE
+                and out is None
+                and ops.conv_wino_supported(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation)):
+            return ops.conv2d_wino(x, self.packed_wino(), bias, residual, act_out=act_out, raw=raw,
+                                   dilation=self.dilation)
         if self.ndim == 3:
             return ops.conv3d(x, self.packed(), bias, coef, act, residual, self.dilation, act_out=act_out, raw=raw)
         return ops.conv2d(x, self.packed(), bias, coef, act, residual, self.dilation, out=out, act_out=act_out, raw=raw)

@@ -324,11 +324,11 @@ def conv_wino_weight(w):
     return U
 
 
-def conv_wino_supported(Cin, Cout, H, W):
-    return bool(_lib.lib.ipdm_conv2d_wino_supported(Cin, Cout, H, W))
+def conv_wino_supported(Cin, Cout, H, W, dilation=1):
+    return bool(_lib.lib.ipdm_conv2d_wino_supported(Cin, Cout, H, W, dilation))
 
 
-def conv2d_wino(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True):
+def conv2d_wino(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dilation=1):
     """3x3 / dilation-1 convolution through the Winograd F(2x2,3x3) kernel (same output options as conv2d)"""
     x = _gpu(x, torch.float32, "x")
     B, Cin, H, W = x.shape
@@ -340,10 +340,10 @@ def conv2d_wino(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     call("ipdm_conv2d_wino_f32", _ptr(x), _ptr(U), _ptr(bias), _ptr(residual), _ptr(out), _ptr(out_act), act_out,
-         B, Cin, Cout, H, W, _stream())
+         B, Cin, Cout, H, W, dilation, _stream())
     if CONV_TRACE is not None:
         e1.record()
-        CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=1, wino=True, e0=e0, e1=e1))
+        CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, e0=e0, e1=e1))
     return (out, out_act) if want_act else out
 
 

@@ -43,10 +43,10 @@ for idx, (cnt, ci, co, hw, dil) in enumerate(SHAPES):
     out = torch.empty(B, co, hw, hw, device="cuda")
     flop = 2.0 * B * hw * hw * ci * co * 9
     t_m = 1e9 if NO_MIOPEN else timeit(lambda: F.conv2d(x, w, bias, padding=dil, dilation=dil))
-    if WINO and dil == 1 and ops.conv_wino_supported(ci, co, hw, hw):
+    if WINO and ops.conv_wino_supported(ci, co, hw, hw, dil):
         U = ops.conv_wino_weight(w)
-        t_o = timeit(lambda: ops.conv2d_wino(x, U, bias))
-        out = ops.conv2d_wino(x, U, bias)
+        t_o = timeit(lambda: ops.conv2d_wino(x, U, bias, dilation=dil))
+        out = ops.conv2d_wino(x, U, bias, dilation=dil)
     elif FUSED and ci > 1:
         coef = torch.randn(B, ci, 3, device="cuda")
         res = torch.randn(B, co, hw, hw, device="cuda")

@@ -359,26 +359,29 @@ def test_conv2d_activated_second_output(ops):
     assert ((got - ref).abs() <= 2e-7 + 2e-6 * ref.abs()).all()
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W,res", [(2, 64, 64, 32, 32, True), (1, 128, 128, 64, 64, False),
-                                                (3, 256, 256, 32, 32, True), (2, 8, 64, 10, 36, False),
-                                                (1, 128, 256, 128, 128, False)])
-def test_conv2d_winograd(ops, B, Cin, Cout, H, W, res):
+@pytest.mark.parametrize("B,Cin,Cout,H,W,res,dil", [
+    (2, 64, 64, 32, 32, True, 1), (1, 128, 128, 64, 64, False, 1), (3, 256, 256, 32, 32, True, 1),
+    (2, 8, 64, 10, 36, False, 1), (1, 128, 256, 128, 128, False, 1),
+    (3, 64, 64, 16, 16, True, 1), (2, 64, 128, 16, 16, True, 2), (2, 128, 64, 16, 16, False, 4),   # small / dilated
+    (1, 16, 64, 24, 16, False, 2), (1, 16, 64, 32, 32, True, 2)])
+def test_conv2d_winograd(ops, B, Cin, Cout, H, W, res, dil):
     """F(2x2,3x3) path vs a float64 direct convolution; also checks the weight transform U = G g G^T"""
-    assert ops.conv_wino_supported(Cin, Cout, H, W)
-    assert not ops.conv_wino_supported(Cin, Cout, 16, 16) and not ops.conv_wino_supported(Cin + 1, Cout, H, W)
+    assert ops.conv_wino_supported(Cin, Cout, H, W, dil)
+    assert not ops.conv_wino_supported(Cin + 1, Cout, H, W, dil) and not ops.conv_wino_supported(Cin, Cout, 18, 16, 4)
     gen = torch.Generator().manual_seed(15)
     x = torch.randn(B, Cin, H, W, generator=gen)
     w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5
     bias = torch.randn(Cout, generator=gen)
     resid = torch.randn(B, Cout, H, W, generator=gen) if res else None
-    want = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    want = F.conv2d(x.double(), w.double(), bias.double(), padding=dil, dilation=dil)
     if res:
         want = want + resid.double()
     U = ops.conv_wino_weight(w.cuda())
     G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
     Uref = torch.einsum("ai,ocij,bj->aboc", G, w.double(), G).reshape(16, Cout, Cin).permute(0, 2, 1)
     assert (U.cpu().double() - Uref).abs().max() < 1e-6
-    raw, act = ops.conv2d_wino(x.cuda(), U, bias.cuda(), None if resid is None else resid.cuda(), act_out=ops.ACT_ELU)
+    raw, act = ops.conv2d_wino(x.cuda(), U, bias.cuda(), None if resid is None else resid.cuda(), act_out=ops.ACT_ELU,
+                               dilation=dil)
     err = (raw.cpu().double() - want).abs().max()
     assert err < 4e-5 * max(1.0, float(want.abs().max())), float(err)
     assert (act.cpu().double() - F.elu(want)).abs().max() < 4e-5 * max(1.0, float(want.abs().max()))
