@@ -207,6 +207,10 @@ int ipdm_conv2d_wino_f32(const float* x, const float* U, const float* bias, cons
                          float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
                          void* stream);
 
+/* tuning aid: when set (device buffer of 4*n_blocks uint64), the Winograd kernel's workgroups write s_memtime stamps
+ * (start, loop start, loop end, end); NULL (default) disables it */
+int ipdm_debug_set_stamp_buffer(void* buf);
+
 /* 3-D variant for the temporal prior (reference: nn.Conv3d(k=3, padding=dilation, dilation) call sites in
  * ncsn/models/layers3d.py and ncsn/models/ncsn3d.py:137,141): x [B][Cin][D][H][W], weights packed by
  * ipdm_conv_pack_weight_f32(k = 27) to [27][Cin][Cout] (k == 1: [1][Cin][Cout]).  Each depth slice is an

@@ -54,6 +54,7 @@ SIGNATURES = {
     "ipdm_conv_wino_weight_f32": [P, P, c_int, c_int, P],
     "ipdm_conv2d_wino_supported": [c_int, c_int, c_int, c_int, c_int],
     "ipdm_conv2d_wino_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "ipdm_debug_set_stamp_buffer": [P],
     "ipdm_conv3d_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 8 + [P],
     "ipdm_maxpool3d5_f32": [P, P, c_int, c_int, c_int, c_int, P],
     "ipdm_temporal_taps_f32": [P, P, c_int, c_int, c_int, c_int, c_int, P],

@@ -94,7 +94,7 @@ extern "C" int ipdm_conv2d_f32(const float* x, const float* wt, const float* bia
   a.x = x; a.wt = wt; a.bias = bias; a.coef = coef; a.residual = residual; a.out = out; a.out_act = out_act; a.act_out = act_out;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = k == 3 ? dilation : 1; a.act = act;
   a.D = 1; a.kd = 1;
-  a.tiles_x = a.tiles_y = a.co_tiles = 0;
+  a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = nullptr;
   return dispatch_conv(a, k, ipdm_stream(stream));
 }
 
@@ -109,11 +109,17 @@ extern "C" int ipdm_conv3d_f32(const float* x, const float* wt, const float* bia
   a.x = x; a.wt = wt; a.bias = bias; a.coef = coef; a.residual = residual; a.out = out; a.out_act = out_act; a.act_out = act_out;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = k == 3 ? dilation : 1; a.act = act;
   a.D = D; a.kd = k;
-  a.tiles_x = a.tiles_y = a.co_tiles = 0;
+  a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = nullptr;
   return dispatch_conv(a, k, ipdm_stream(stream));
 }
 
 // ---- Winograd F(2x2, 3x3) entry points (conv_wino.hip) ---------------------------------------------------------
+static unsigned long long* g_wino_dbg = nullptr;
+// tuning aid: a device buffer of 4 * n_blocks uint64 receives (start, loop start, loop end, end) s_memtime stamps
+extern "C" int ipdm_debug_set_stamp_buffer(void* buf) {
+  g_wino_dbg = (unsigned long long*)buf;
+  return IPDM_OK;
+}
 extern "C" int ipdm_conv_wino_weight_f32(const float* w, float* U, int Cout, int Cin, void* stream) {
   IPDM_REQUIRE(w && U && Cout > 0 && Cin > 0);
   return conv_wino_weights(w, U, Cout, Cin, ipdm_stream(stream));
@@ -122,6 +128,7 @@ extern "C" int ipdm_conv_wino_weight_f32(const float* w, float* U, int Cout, int
 extern "C" int ipdm_conv2d_wino_supported(int Cin, int Cout, int H, int W, int dilation) {
   ConvArgs a;
   a.coef = nullptr; a.act = IPDM_ACT_NONE; a.dil = dilation; a.D = 1; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.B = 1;                       // the per-launch size limit (buffer descriptors) is checked again with the real batch
   return wino_ok(a, 3) ? 1 : 0;
 }
 
@@ -134,7 +141,7 @@ extern "C" int ipdm_conv2d_wino_f32(const float* x, const float* U, const float*
   ConvArgs a;
   a.x = x; a.wt = U; a.bias = bias; a.coef = nullptr; a.residual = residual; a.out = out; a.out_act = out_act;
   a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = dilation; a.act = IPDM_ACT_NONE;
-  a.D = 1; a.kd = 1; a.tiles_x = a.tiles_y = a.co_tiles = 0;
+  a.D = 1; a.kd = 1; a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = g_wino_dbg; a.dbg = g_wino_dbg;
   if (!wino_ok(a, 3)) return IPDM_EUNSUPPORTED;
   return conv_wino_launch(a, ipdm_stream(stream));
 }

@@ -32,6 +32,7 @@ struct ConvArgs {
   int B, Cin, Cout, H, W, dil, act;
   int D, kd;       // depth slices per volume (1 = plain 2-D) and depth taps (1 or 3): 3-D convolution as extra K chunks
   int tiles_x, tiles_y, co_tiles;
+  unsigned long long* dbg;   // optional in-kernel stamps (diagnostic builds / IPDM tuning only; NULL in production)
 };
 
 // NCT x NPT MFMA tiles per wave, WCO x WPX waves (WCO*WPX == 4), PW = pixel-tile width (16 or 32),

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
   const int b_base = W_U_ELEMS + (ph * 8 * W_KC + h) * W_TILES + wtl * 32 + j;     // Vs[p][kc][tile]
 
   // ---- staging geometry: this thread transforms tile `mytile` of channel kc = tid / 64 ----
-  const int mytile = tid & 63, kc_a = tid >> 6;
+  const int mytile = tid & 63;
+  const int kc_a = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the channel base pointer in SGPRs
   const int tyl = mytile / W_TX, txl = mytile % W_TX;
   // 4x4 patch addresses = (clamped row offset) + (clamped column offset); padding is zero-selected after the load
   int row_off[4], col_off[4];
@@ -116,11 +117,22 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
     rv |= oky ? (1u << e) : 0u;
     cv |= okx ? (1u << e) : 0u;
   }
+  // Patch loads are BUFFER loads: 128-bit descriptor in SGPRs + 32-bit per-lane byte offset + scalar chunk offset, so
+  // no 64-bit address VALU in the loop, and zero padding comes from the hardware range check (offset past the end of
+  // the tensor returns 0) instead of a select.
+  int p_boff[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) p_valid |= (((rv >> (e / 4)) & (cv >> (e % 4))) & 1u) << e;
+  for (int e = 0; e < 16; ++e) {
+    const bool ok = (((rv >> (e / 4)) & (cv >> (e % 4))) & 1u) != 0;
+    p_valid |= ok ? (1u << e) : 0u;
+    p_boff[e] = ok ? (row_off[e / 4] + col_off[e % 4]) * 4 : 0x7ffffff0;
+  }
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((size_t)a.B * a.Cin * HW * 4), 0x00020000);
+
   // U chunk: float4 number v = tid + i*512 of the [16 pos][8 kc][64 co] block; consecutive i are 4 positions apart
-  const int u_gofs0 = ((tid >> 7) * a.Cin + ((tid >> 4) & 7)) * a.Cout + (tid & 15) * 4;
-  const int u_stride = 4 * a.Cin * a.Cout;
+  const int u_boff0 = (((tid >> 7) * a.Cin + ((tid >> 4) & 7)) * a.Cout + (tid & 15) * 4 + co0) * 4;   // bytes
+  const int u_bstride = 4 * a.Cin * a.Cout * 4;
 
   f32x16 acc[8];
 #pragma unroll
@@ -131,20 +143,29 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
   float ureg[4][4];
   float dreg[16];
 
-  auto load_chunk = [&](int c0) {
-    const float* ub = a.wt + (size_t)c0 * a.Cout + co0;
+  // loads of one chunk in three parts (issued inside the first three MFMA groups of the previous chunk)
+  auto load_part = [&](int c0, auto partc) {
+    constexpr int part = decltype(partc)::value;
+    if constexpr (part == 0) {
+      // (ROCm 7.2's __builtin_amdgcn_raw_buffer_load_b128 lowers to a single-dword load: the weights keep plain
+      //  16-byte global loads)
+      const char* ub = reinterpret_cast<const char*>(a.wt) + (size_t)c0 * a.Cout * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 t4 = *reinterpret_cast<const float4*>(ub + u_gofs0 + (size_t)i * u_stride);
-      ureg[i][0] = t4.x; ureg[i][1] = t4.y; ureg[i][2] = t4.z; ureg[i][3] = t4.w;
+      for (int i = 0; i < 4; ++i) {
+        const float4 t4 = *reinterpret_cast<const float4*>(ub + u_boff0 + (size_t)i * u_bstride);
+        ureg[i][0] = t4.x; ureg[i][1] = t4.y; ureg[i][2] = t4.z; ureg[i][3] = t4.w;
+      }
+    } else {
+      const int soff = (int)(((size_t)b * a.Cin + c0 + kc_a) * HW * 4);
+#pragma unroll
+      for (int e = (part - 1) * 8; e < part * 8; ++e)
+        dreg[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, p_boff[e], soff, 0));
     }
-    // keep the (L2-resident) weight loads AHEAD of the (HBM) patch loads: vmcnt retires in issue order and the
-    // weight pieces are consumed first -- hipcc otherwise hoists the patch loads in front
-    __builtin_amdgcn_sched_barrier(0);
-    const float* xa = a.x + ((size_t)b * a.Cin + c0 + kc_a) * HW;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) dreg[e] = xa[row_off[e / 4] + col_off[e % 4]];
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto load_chunk = [&](int c0) {
+    load_part(c0, std::integral_constant<int, 0>{});
+    load_part(c0, std::integral_constant<int, 1>{});
+    load_part(c0, std::integral_constant<int, 2>{});
   };
 
   // pieces 0..3: one float4 of U each; piece 4: B^T d B of this thread's (channel, tile) pair -> 16 LDS words
@@ -153,9 +174,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
     if constexpr (q < 4) {
       reinterpret_cast<float4*>(st)[tid + q * 512] = make_float4(ureg[q][0], ureg[q][1], ureg[q][2], ureg[q][3]);
     } else {
-      float d[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) d[e] = (p_valid >> e) & 1u ? dreg[e] : 0.f;
+      const float(&d)[16] = dreg;          // padding already reads as 0 (buffer range check)
       float tmp[16];                       // B^T d : rows (d0-d2, d1+d2, d2-d1, d1-d3)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -186,7 +205,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
     }
   };
   constexpr int GROUPS = 8, PIECES = 5, FIRST = GROUPS - PIECES;
-  auto compute = [&](const float* cur, float* nxt, auto store_flag) {
+  auto compute = [&](const float* cur, float* nxt, int c0_next, auto store_flag) {
     constexpr bool STORE = decltype(store_flag)::value;
     float av[2][4], bv[2][4];
     load_ops(cur, std::integral_constant<int, 0>{}, av[0], bv[0]);
@@ -196,6 +215,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
       constexpr int pg = g % 2;
       if constexpr (g + 1 < GROUPS) load_ops(cur, std::integral_constant<int, g + 1>{}, av[(g + 1) & 1], bv[(g + 1) & 1]);
       constexpr bool HAS_STORE = STORE && g >= FIRST;
+      constexpr bool HAS_LOAD = STORE && g < 3;            // next chunk's global loads ride in groups 0..2
+      if constexpr (HAS_LOAD) load_part(c0_next, std::integral_constant<int, g>{});
       if constexpr (HAS_STORE) store_piece(nxt, std::integral_constant<int, g - FIRST>{});
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -205,7 +226,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if constexpr (HAS_STORE) __builtin_amdgcn_sched_group_barrier(0x006, IS_V ? 16 : 2, 0);
+        if constexpr (HAS_STORE) __builtin_amdgcn_sched_group_barrier(0x006, IS_V ? 12 : 2, 0);
+        if constexpr (HAS_LOAD) {
+          __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, g == 0 ? 1 : 2, 0);
+        }
       }
       if constexpr (HAS_STORE) __builtin_amdgcn_sched_group_barrier(0x200, IS_V ? 16 : 1, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -213,17 +238,20 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
   };
 
   const int n_chunks = a.Cin / W_KC;
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  if (a.dbg) t0 = __builtin_amdgcn_s_memtime();
   load_chunk(0);
   static_for<PIECES>([&](auto qc) { store_piece(lds, qc); });
   __syncthreads();
+  if (a.dbg) t1 = __builtin_amdgcn_s_memtime();
   for (int ch = 0; ch + 1 < n_chunks; ++ch) {
     float* cur = lds + (ch & 1) * W_STAGE;
     float* nxt = lds + ((ch + 1) & 1) * W_STAGE;
-    load_chunk((ch + 1) * W_KC);
-    compute(cur, nxt, std::true_type{});
+    compute(cur, nxt, (ch + 1) * W_KC, std::true_type{});
     __syncthreads();
   }
-  compute(lds + ((n_chunks - 1) & 1) * W_STAGE, nullptr, std::false_type{});
+  compute(lds + ((n_chunks - 1) & 1) * W_STAGE, nullptr, 0, std::false_type{});
+  if (a.dbg) t2 = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue: each wave reduces its 8 positions (rows 2ph, 2ph+1 of M) to a partial Y = A^T M A, the ph = 1
   //      wave hands its partial to the ph = 0 wave through LDS, which adds bias / residual and stores float2 ----
@@ -255,22 +283,32 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
       yv[r][i * 2 + 1] = tt[i][1] - tt[i][2] - tt[i][3];
     }
   }
-  if (ph == 1) {
+  // both waves of a pair finalize half of the 16 channel rows: wave ph keeps rows 8*ph .. 8*ph+7 and hands the
+  // partials of the other 8 rows to its partner
+  float* ex_out = ex + ((1 - ph) * 8 * 4) * 64;          // slots the PARTNER will read: [8 rows][4][lane]
+  float* ex_in = ex + (ph * 8 * 4) * 64;
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
+  for (int rr = 0; rr < 8; ++rr) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) ex[(r * 4 + v) * 64 + lane] = yv[r][v];
+    for (int v = 0; v < 4; ++v) {
+      // static register indexing: select the row of the other half without a runtime index
+      const float val = ph == 0 ? yv[8 + rr][v] : yv[rr][v];
+      ex_out[(rr * 4 + v) * 64 + lane] = val;
+    }
   }
   __syncthreads();
-  if (ph == 0 && out_ok) {
+  if (out_ok) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = ph * 8 + rr;
       const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       const float bias = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        float y0v = yv[r][i * 2 + 0] + ex[(r * 4 + i * 2 + 0) * 64 + lane] + bias;
-        float y1v = yv[r][i * 2 + 1] + ex[(r * 4 + i * 2 + 1) * 64 + lane] + bias;
+        const float own0 = ph == 0 ? yv[rr][i * 2 + 0] : yv[8 + rr][i * 2 + 0];
+        const float own1 = ph == 0 ? yv[rr][i * 2 + 1] : yv[8 + rr][i * 2 + 1];
+        float y0v = own0 + ex_in[(rr * 4 + i * 2 + 0) * 64 + lane] + bias;
+        float y1v = own1 + ex_in[(rr * 4 + i * 2 + 1) * 64 + lane] + bias;
         const size_t o = ((size_t)b * a.Cout + co) * HW + (size_t)(oy + (SMALL ? d * i : i)) * a.W + ox;
         if constexpr (SMALL) {                 // the two outputs of a tile row are d pixels apart
           if (a.residual) {
@@ -287,9 +325,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
           }
         } else {
           if (a.residual) {
-            const float2 rr = *reinterpret_cast<const float2*>(a.residual + o);
-            y0v += rr.x;
-            y1v += rr.y;
+            const float2 rr2 = *reinterpret_cast<const float2*>(a.residual + o);
+            y0v += rr2.x;
+            y1v += rr2.y;
           }
           if (a.out) *reinterpret_cast<float2*>(a.out + o) = make_float2(y0v, y1v);
           if (a.out_act) {
@@ -300,6 +338,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
         }
       }
     }
+  }
+  if (a.dbg && tid == 0) {
+    unsigned long long* d4 = a.dbg + (size_t)blockIdx.x * 4;
+    d4[0] = t0; d4[1] = t1; d4[2] = t2; d4[3] = __builtin_amdgcn_s_memtime();
   }
 }
 
@@ -313,6 +355,7 @@ static bool wino_small(const ConvArgs& a) {
 bool wino_ok(const ConvArgs& a, int ks) {
   if (!(ks == 3 && a.D == 1 && a.Cin % W_KC == 0 && a.Cout % W_CO == 0 && !a.coef && a.act == IPDM_ACT_NONE)) return false;
   if (a.dil < 1 || a.dil > 4) return false;
+  if ((size_t)a.B * a.Cin * a.H * a.W * 4 >= 0x7fffffffull) return false;   // buffer descriptors address < 2 GiB
   if (wino_small(a)) return a.H % (2 * a.dil) == 0 && a.W % (2 * a.dil) == 0 && (a.H * a.W) / 4 >= 32;
   return a.H % 2 == 0 && a.W % 2 == 0 && a.H >= 8;
 }
