@@ -226,6 +226,21 @@ int ipdm_maxpool3d5_f32(const float* x, float* y, int planes, int D, int H, int 
  * A 1x1 ipdm_conv2d_f32 over the 4*C gathered channels then IS the temporal convolution. */
 int ipdm_temporal_taps_f32(const float* x, float* out, int planes, int S, int T_in, int T_out, int mode, void* stream);
 
+/* ---- fp32 convolution on the bf16 matrix cores ("bf16x3": exact three-way operand split, six
+ * v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulation; fp32-faithful results at 2.67x the fp32 MFMA rate) ----
+ * Same call sites, arguments and fused input / output options as ipdm_conv2d_f32 / ipdm_conv3d_f32; only the
+ * packed-weight format differs: an opaque blob of ipdm_conv_bx3_weight_bytes(Cout, Cin, k) bytes written by
+ * ipdm_conv_bx3_pack_weight (k = 1, 3, or 27 for a 3x3x3 kernel), valid for every batch / image size. */
+int64_t ipdm_conv_bx3_weight_bytes(int Cout, int Cin, int k);
+int ipdm_conv_bx3_pack_weight(const float* w /* [Cout][Cin][k][k] or [Cout][Cin][3][3][3] */, void* packed, int Cout,
+                              int Cin, int k, void* stream);
+int ipdm_conv2d_bx3_f32(const float* x, const void* packed, const float* bias, const float* coef, int act,
+                        const float* residual, float* out, float* out_act, int act_out,
+                        int B, int Cin, int Cout, int H, int W, int k, int dilation, void* stream);
+int ipdm_conv3d_bx3_f32(const float* x, const void* packed, const float* bias, const float* coef, int act,
+                        const float* residual, float* out, float* out_act, int act_out,
+                        int B, int Cin, int Cout, int D, int H, int W, int k, int dilation, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,7 @@ extern "C" int ipdm_conv3d_f32(const float* x, const float* wt, const float* bia
 
 // ---- Winograd F(2x2, 3x3) entry points (conv_wino.hip) ---------------------------------------------------------
 static unsigned long long* g_wino_dbg = nullptr;
+namespace ipdm_conv { unsigned long long* conv_debug_stamps() { return g_wino_dbg; } }
 // tuning aid: a device buffer of 4 * n_blocks uint64 receives (start, loop start, loop end, end) s_memtime stamps
 extern "C" int ipdm_debug_set_stamp_buffer(void* buf) {
   g_wino_dbg = (unsigned long long*)buf;

@@ -1,0 +1,447 @@
+// fp32 convolution on the gfx950 bf16 matrix cores by exact operand splitting ("bf16x3").
+//
+// The fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 rate (157 TFLOP/s vs ~2.5 PFLOP/s), so the dense
+// 3x3 / 1x1 contractions are computed here as
+//     x = xh + xm + xl,   xh = bf16(x), xm = bf16(x - xh), xl = bf16(x - xh - xm)      (8 + 8 + 8 significand bits:
+//     the three pieces carry the whole fp32 significand; both subtractions are exact in fp32)
+//     w * x = wh*xh + (wh*xm + wm*xh) + (wh*xl + wm*xm + wl*xh) + O(2^-27 |w x|)
+// i.e. SIX v_mfma_f32_32x32x16_bf16 per 32x32x16 tile, accumulated in fp32 (every bf16 x bf16 product is exact in
+// fp32).  The three dropped products are below 2^-26 relative -- less than the rounding of one fp32 fma -- so the
+// result is fp32-faithful: tests/test_kernels_gpu.py holds it to the same float64-referenced bound as the fp32 MFMA
+// kernel.  6 x 32 cycles per 16-deep k-step against 8 x 64 for the fp32 instruction: 2.67x the matrix rate.
+//
+// GEMM view (as conv_kernel.h):  D[co, pixel] = sum_{tap, ci} W[tap][ci][co] * P[ci][pixel + tap offset]
+//   A operand (32 x 16): rows = output channels, k = 16 input channels; lane (r, h) holds k = 8h .. 8h+7 of row r.
+//        Weights are split and laid out ONCE by ipdm_conv_bx3_pack_weight so that a wave's fragment is one
+//        contiguous KiB: [tap][ci/16][co/32][piece][h][r][8 x bf16].  Fragments go global -> VGPR directly
+//        (global_load_dwordx4, prefetched one tap ahead); they never touch LDS.
+//   B operand (16 x 32): k = the same 16 channels, columns = 32 pixels.  The input patch (+halo) of a 16-channel
+//        chunk is loaded NCHW-coalesced (lane <-> pixel), activated/normalised if asked, split, and stored to LDS
+//        channel-innermost: [piece][h][patch pixel][8 x bf16] -- so every tap's operand read is ONE conflict-free
+//        ds_read_b128 per piece at a shifted pixel address.  Double-buffered; one barrier per chunk.
+//   accumulator: lane <-> pixel, registers <-> output channels (coalesced NCHW stores), as the fp32 kernel.
+// Two workgroups per CU (<= 256 registers, <= 80 KiB LDS): one wave's staging / waits run under the other's MFMAs.
+#include "conv_kernel.h"
+
+namespace ipdm_conv {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS>
+struct BxCfg {
+  static constexpr int TAPS = KS * KS;
+  static constexpr int CO_T = 32 * NCT * WCO;
+  static constexpr int ROWS_PER_TILE = 32 / PW;
+  static constexpr int PH = NPT * WPX * ROWS_PER_TILE;
+  static constexpr int HALO = KS == 3 ? DMAX : 0;
+  static constexpr int PHP = PH + 2 * HALO;
+  static constexpr int PWP = PW + 2 * HALO;
+  // PW == 16: a 32-lane half reads two image rows; a pitch of 0 (mod 16) pixels keeps their 16-byte pieces on
+  // disjoint banks for ds_read_b128's lane groups
+  static constexpr int PITCH = PW == 32 ? PWP : (PWP + 15) / 16 * 16;
+  static constexpr int PLANE = PHP * PITCH;                  // 16-byte units
+  static constexpr int STAGE = 6 * PLANE;                    // [piece 3][h 2][PLANE]
+  static constexpr int ITEMS = (2 * PHP * PWP + 255) / 256;  // (pixel, 8-channel group) items per thread
+  static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE * 16;
+};
+
+__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 hi = (__bf16)v[i];
+    const float r1 = v[i] - (float)hi;
+    const __bf16 mi = (__bf16)r1;
+    const float r2 = r1 - (float)mi;
+    h[i] = hi;
+    m[i] = mi;
+    l[i] = (__bf16)r2;
+  }
+}
+
+template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS, bool FAST>
+__global__ __launch_bounds__(256, (NCT * NPT <= 2 ? 4 : 2)) void conv_bx3_kernel(ConvArgs a) {
+  using C = BxCfg<NCT, NPT, WCO, WPX, PW, DMAX, KS>;
+  static_assert(WCO * WPX == 4, "four waves per workgroup");
+  extern __shared__ __align__(16) uint4 lds4[];
+
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  if (a.dbg) t0 = __builtin_amdgcn_s_memtime();
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, slot = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int co_tile = bid % a.co_tiles;
+  int t = bid / a.co_tiles;
+  const int tx = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int ty = t % a.tiles_y;
+  const int bz = t / a.tiles_y;
+  const int b = bz / a.D, z = bz - b * a.D;
+  const int y0 = ty * C::PH, x0 = tx * PW;
+  const int d = KS == 3 ? (DMAX == 1 ? 1 : a.dil) : 0;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const int wco = wave / WPX, wpx = wave % WPX;
+  const int HW = a.H * a.W;
+  const size_t cs = (size_t)a.D * HW;
+
+  const int n_cc = (a.Cin + 15) / 16;
+  const int n_ct = (a.Cout + 31) / 32;
+  // depth taps whose input slice exists (3-D only): a contiguous range around the centre tap
+  int kz_lo = 0, n_kz = 1;
+  if (a.kd == 3) {
+    const bool lo = z - a.dil >= 0, hi = z + a.dil < a.D;
+    kz_lo = lo ? 0 : 1;
+    n_kz = 1 + (lo ? 1 : 0) + (hi ? 1 : 0);
+  }
+  const int n_chunks = n_cc * n_kz;
+
+  // ---- B operand read offsets (16-byte units inside a stage) ----
+  int b_base[NPT];
+#pragma unroll
+  for (int n = 0; n < NPT; ++n) {
+    const int tile = wpx * NPT + n;
+    const int prow = PW == 32 ? tile : tile * 2 + (j >> 4);
+    const int pcol = PW == 32 ? j : (j & 15);
+    b_base[n] = h * C::PLANE + (prow + d) * C::PITCH + pcol + d;
+  }
+
+  // ---- staging geometry: item i = (patch pixel p, channel group g) ----
+  const int pwv = PW + 2 * d, phv = C::PH + 2 * d;
+  const int npos = phv * pwv;
+  int it_lds[C::ITEMS], it_gofs[C::ITEMS], it_g[C::ITEMS];
+  bool it_valid[C::ITEMS];
+#pragma unroll
+  for (int i = 0; i < C::ITEMS; ++i) {
+    int idx = tid + i * 256;
+    idx = idx < 2 * npos ? idx : 2 * npos - 1;
+    const int g = idx >= npos ? 1 : 0;
+    const int p = idx - g * npos;
+    const int r = p / pwv, c = p - r * pwv;
+    const int gy = y0 - d + r, gx = x0 - d + c;
+    it_g[i] = g;
+    it_lds[i] = g * C::PLANE + r * C::PITCH + c;
+    it_valid[i] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    it_gofs[i] = it_valid[i] ? gy * a.W + gx : 0;
+  }
+
+  float preg[C::ITEMS][8];
+  auto chunk_kz_c0 = [&](int ch, int& kz, int& c0) {
+    const int kzi = ch / n_cc;
+    c0 = (ch - kzi * n_cc) * 16;
+    kz = kz_lo + kzi;
+  };
+  auto load_chunk = [&](int ch) {
+    int kz, c0;
+    chunk_kz_c0(ch, kz, c0);
+    const int zi = z + (kz - a.kd / 2) * a.dil;
+    const float* xb = a.x + (((size_t)b * a.Cin + c0) * a.D + zi) * HW;
+#pragma unroll
+    for (int i = 0; i < C::ITEMS; ++i) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int cl = it_g[i] * 8 + q;
+        if constexpr (FAST) {
+          preg[i][q] = xb[(size_t)cl * cs + it_gofs[i]];
+        } else {
+          float v = 0.f;
+          if (it_valid[i] && c0 + cl < a.Cin) v = xb[(size_t)cl * cs + it_gofs[i]];
+          preg[i][q] = v;
+        }
+      }
+    }
+  };
+  auto store_chunk = [&](uint4* st, int ch) {
+    int kz, c0;
+    chunk_kz_c0(ch, kz, c0);
+#pragma unroll
+    for (int i = 0; i < C::ITEMS; ++i) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float val = preg[i][q];
+        if constexpr (FAST) {
+          val = it_valid[i] ? val : 0.f;
+        } else {
+          const int ci = c0 + it_g[i] * 8 + q;
+          if (it_valid[i] && ci < a.Cin) {
+            if (a.coef) {
+              const float* cf = a.coef + ((size_t)b * a.Cin + ci) * 3;
+              val = (val - cf[0]) * cf[1] + cf[2];
+            }
+            val = a.act == IPDM_ACT_ELU ? fast_elu(val) : ipdm_act(val, a.act);
+          } else {
+            val = 0.f;
+          }
+        }
+        v[q] = val;
+      }
+      bf16x8 ph, pm, pl;
+      split3(v, ph, pm, pl);
+      st[it_lds[i]] = __builtin_bit_cast(uint4, ph);
+      st[2 * C::PLANE + it_lds[i]] = __builtin_bit_cast(uint4, pm);
+      st[4 * C::PLANE + it_lds[i]] = __builtin_bit_cast(uint4, pl);
+    }
+  };
+
+  // ---- A fragments: global -> VGPR, [tapidx][cc][ct][piece][lane] in 16-byte units ----
+  const uint4* wq = reinterpret_cast<const uint4*>(a.wt);
+  const int ct0 = (co_tile * WCO + wco) * NCT;
+  const size_t tap_stride = (size_t)n_cc * n_ct * 192;
+  int ct_ofs[NCT];
+#pragma unroll
+  for (int m = 0; m < NCT; ++m) ct_ofs[m] = (ct0 + m < n_ct ? ct0 + m : n_ct - 1) * 192 + lane;   // ragged: reload a valid one
+  auto a_chunk_ptr = [&](int ch) {
+    int kz, c0;
+    chunk_kz_c0(ch, kz, c0);
+    return wq + ((size_t)kz * C::TAPS * n_cc + (c0 >> 4)) * n_ct * 192;
+  };
+  auto load_A = [&](bf16x8 (&fr)[NCT][3], const uint4* base, int tap) {
+    const uint4* p = base + tap * tap_stride;
+#pragma unroll
+    for (int m = 0; m < NCT; ++m)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) fr[m][s] = __builtin_bit_cast(bf16x8, p[ct_ofs[m] + s * 64]);
+  };
+
+  f32x16 acc[NCT][NPT];
+#pragma unroll
+  for (int m = 0; m < NCT; ++m)
+#pragma unroll
+    for (int n = 0; n < NPT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  bf16x8 afr[2][NCT][3];
+  bf16x8 bfr[2][3];
+  load_A(afr[0], a_chunk_ptr(0), 0);
+  load_chunk(0);
+  store_chunk(lds4, 0);
+  __syncthreads();
+
+  if (a.dbg) t1 = __builtin_amdgcn_s_memtime();
+  constexpr int STEPS = C::TAPS * NPT;
+  // operand reads of step s = (tap, pixel tile n): one ds_read_b128 per piece at the tap-shifted pixel
+  auto load_B = [&](bf16x8 (&fr)[3], const uint4* cur, auto sc) {
+    constexpr int st = decltype(sc)::value;
+    constexpr int tap = st / NPT, n = st % NPT;
+    constexpr int dy = KS == 3 ? tap / 3 - 1 : 0, dx = KS == 3 ? tap % 3 - 1 : 0;
+    const uint4* bp = cur + b_base[n] + (dy * C::PITCH + dx) * d;
+    fr[0] = __builtin_bit_cast(bf16x8, bp[0]);
+    fr[1] = __builtin_bit_cast(bf16x8, bp[2 * C::PLANE]);
+    fr[2] = __builtin_bit_cast(bf16x8, bp[4 * C::PLANE]);
+  };
+
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    const uint4* cur = lds4 + (ch & 1) * C::STAGE;
+    uint4* nxt = lds4 + ((ch + 1) & 1) * C::STAGE;
+    const bool more = ch + 1 < n_chunks;
+    const uint4* a_cur = a_chunk_ptr(ch);
+    const uint4* a_nxt = a_chunk_ptr(more ? ch + 1 : ch);
+    if (more) load_chunk(ch + 1);
+    load_B(bfr[0], cur, std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    // Software pipeline pinned with sched_group_barrier: the LDS reads of step s+1 (and, at the first step of a
+    // tap, the global loads of the NEXT tap's A fragments) are issued before the six MFMAs of step s.
+    static_for<STEPS>([&](auto sc) {
+      constexpr int st = decltype(sc)::value;
+      constexpr int tap = st / NPT, n = st % NPT;
+      if constexpr (st + 1 < STEPS) load_B(bfr[(st + 1) & 1], cur, std::integral_constant<int, st + 1>{});
+      if constexpr (n == 0) {
+        if constexpr (tap + 1 < C::TAPS) load_A(afr[(tap + 1) & 1], a_cur, tap + 1);
+        else load_A(afr[(tap + 1) & 1], a_nxt, 0);
+      }
+      const bf16x8 bh = bfr[st & 1][0], bm = bfr[st & 1][1], bl = bfr[st & 1][2];
+#pragma unroll
+      for (int m = 0; m < NCT; ++m) {
+        const bf16x8 ah = afr[tap & 1][m][0], am = afr[tap & 1][m][1], al = afr[tap & 1][m][2];
+        f32x16 c = acc[m][n];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+        acc[m][n] = c;
+      }
+      if constexpr (st + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);          // DS reads first
+      if constexpr (n == 0) __builtin_amdgcn_sched_group_barrier(0x020, 3 * NCT, 0);            // then the A loads
+      __builtin_amdgcn_sched_group_barrier(0x008, 6 * NCT, 0);                                  // then the MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr ((C::TAPS & 1) == 1) {            // the prefetched tap-0 fragments of the next chunk sit in slot 1
+#pragma unroll
+      for (int m = 0; m < NCT; ++m)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) afr[0][m][s] = afr[1][m][s];
+    }
+    if (more) store_chunk(nxt, ch + 1);
+    __syncthreads();
+  }
+
+  if (a.dbg) t2 = __builtin_amdgcn_s_memtime();
+  // ---- epilogue: bias, residual, coalesced stores (lane <-> pixel) ----
+  const int co0 = co_tile * C::CO_T;
+#pragma unroll
+  for (int n = 0; n < NPT; ++n) {
+    const int tile = wpx * NPT + n;
+    const int prow = PW == 32 ? tile : tile * 2 + (j >> 4);
+    const int pcol = PW == 32 ? j : (j & 15);
+    const int gy = y0 + prow, gx = x0 + pcol;
+    if (gy >= a.H || gx >= a.W) continue;
+#pragma unroll
+    for (int m = 0; m < NCT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wco * NCT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < a.Cout) {
+          const size_t o = (((size_t)b * a.Cout + co) * a.D + z) * HW + (size_t)gy * a.W + gx;
+          float v = acc[m][n][r];
+          if (a.bias) v += a.bias[co];
+          if (a.residual) v += a.residual[o];
+          if (a.out) a.out[o] = v;
+          if (a.out_act) a.out_act[o] = a.act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, a.act_out);
+        }
+      }
+    }
+  }
+  if (a.dbg) {                                   // tuning aid (ipdm_debug_set_stamp_buffer); NULL in production
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      unsigned long long* d4 = a.dbg + (size_t)blockIdx.x * 4;
+      d4[0] = t0; d4[1] = t1; d4[2] = t2; d4[3] = t3;
+    }
+  }
+}
+
+template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS, bool FAST>
+int launch_bx3(ConvArgs a, hipStream_t s) {
+  using C = BxCfg<NCT, NPT, WCO, WPX, PW, DMAX, KS>;
+  a.tiles_x = (a.W + PW - 1) / PW;
+  a.tiles_y = (a.H + C::PH - 1) / C::PH;
+  a.co_tiles = (a.Cout + C::CO_T - 1) / C::CO_T;
+  const int64_t nblk = (int64_t)a.B * a.D * a.tiles_x * a.tiles_y * a.co_tiles;
+  if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
+  auto kern = conv_bx3_kernel<NCT, NPT, WCO, WPX, PW, DMAX, KS, FAST>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (C::LDS_BYTES > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)C::LDS_BYTES);
+      if (e != hipSuccess) return (int)e;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, s, a);
+  return ipdm_launch_status();
+}
+
+template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX>
+int launch_bx3_cfg(const ConvArgs& a, int ks, hipStream_t s) {
+  const bool fast = a.Cin % 16 == 0 && a.act == IPDM_ACT_NONE && !a.coef;
+  if (ks == 3) {
+    return fast ? launch_bx3<NCT, NPT, WCO, WPX, PW, DMAX, 3, true>(a, s)
+                : launch_bx3<NCT, NPT, WCO, WPX, PW, DMAX, 3, false>(a, s);
+  }
+  return fast ? launch_bx3<NCT, NPT, WCO, WPX, PW, 1, 1, true>(a, s) : launch_bx3<NCT, NPT, WCO, WPX, PW, 1, 1, false>(a, s);
+}
+
+static int bx3_forced_cfg() {
+  static int v = -2;
+  if (v == -2) {
+    const char* e = getenv("IPDM_BX3_CFG");
+    v = e ? atoi(e) : -1;
+  }
+  return v;
+}
+
+int conv_bx3_dispatch(const ConvArgs& a, int ks, hipStream_t s) {
+  const int f = bx3_forced_cfg();
+  if (a.W <= 16) {
+    if (a.dil > 1 && ks == 3) return launch_bx3_cfg<1, 2, 2, 2, 16, 4>(a, ks, s);    // 64 co x (8 x 16) px
+    return launch_bx3_cfg<1, 2, 2, 2, 16, 1>(a, ks, s);
+  }
+  if (a.dil > 1 && ks == 3) return launch_bx3_cfg<1, 4, 2, 2, 32, 4>(a, ks, s);
+  if (f == 1) return launch_bx3_cfg<1, 2, 1, 4, 32, 1>(a, ks, s);                    // 32 co x 256 px
+  if (f == 2) return launch_bx3_cfg<2, 2, 2, 2, 32, 1>(a, ks, s);                    // 128 co x 128 px
+  if (f == 3) return launch_bx3_cfg<1, 2, 2, 2, 32, 1>(a, ks, s);                    // 64 co x 128 px, 4 workgroups / CU
+  if (a.Cout <= 32) return launch_bx3_cfg<1, 2, 1, 4, 32, 1>(a, ks, s);
+  return launch_bx3_cfg<1, 4, 2, 2, 32, 1>(a, ks, s);                                // 64 co x (8 x 32) px
+}
+
+__global__ __launch_bounds__(256) void bx3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                       int Cout, int Cin, int kk, int n_cc, int n_ct) {
+  const int64_t total = (int64_t)kk * n_cc * n_ct * 512;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int q = (int)(i & 7), r = (int)((i >> 3) & 31), h = (int)((i >> 8) & 1);
+    const int64_t rest = i >> 9;
+    const int ct = (int)(rest % n_ct);
+    const int cc = (int)((rest / n_ct) % n_cc);
+    const int tap = (int)(rest / ((int64_t)n_ct * n_cc));
+    const int co = ct * 32 + r, ci = cc * 16 + 8 * h + q;
+    const float v = (co < Cout && ci < Cin) ? w[((int64_t)co * Cin + ci) * kk + tap] : 0.f;
+    const __bf16 hi = (__bf16)v;
+    const float r1 = v - (float)hi;
+    const __bf16 mi = (__bf16)r1;
+    const __bf16 lo = (__bf16)(r1 - (float)mi);
+    const int64_t base = rest * 3 * 512 + h * 256 + r * 8 + q;
+    out[base] = __builtin_bit_cast(unsigned short, hi);
+    out[base + 512] = __builtin_bit_cast(unsigned short, mi);
+    out[base + 1024] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+
+}  // namespace ipdm_conv
+
+using namespace ipdm_conv;
+
+extern "C" int64_t ipdm_conv_bx3_weight_bytes(int Cout, int Cin, int k) {
+  if (Cout <= 0 || Cin <= 0 || !(k == 1 || k == 3 || k == 27)) return -1;
+  const int64_t kk = k == 27 ? 27 : k * k;
+  return kk * ((Cin + 15) / 16) * ((Cout + 31) / 32) * 3072;
+}
+
+extern "C" int ipdm_conv_bx3_pack_weight(const float* w, void* packed, int Cout, int Cin, int k, void* stream) {
+  IPDM_REQUIRE(w && packed && Cout > 0 && Cin > 0 && (k == 1 || k == 3 || k == 27));
+  const int kk = k == 27 ? 27 : k * k;
+  const int n_cc = (Cin + 15) / 16, n_ct = (Cout + 31) / 32;
+  const int64_t total = (int64_t)kk * n_cc * n_ct * 512;
+  hipLaunchKernelGGL(bx3_pack_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, ipdm_stream(stream), w,
+                     (unsigned short*)packed, Cout, Cin, kk, n_cc, n_ct);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_conv3d_bx3_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
+                                   const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
+                                   int Cout, int D, int H, int W, int k, int dilation, void* stream) {
+  IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0 && (k == 1 || k == 3) && dilation >= 1);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && wq && (out || out_act) && x != out && x != out_act);
+  if (k == 3 && dilation > 4) return IPDM_EUNSUPPORTED;
+  ConvArgs a;
+  a.x = x; a.wt = (const float*)wq; a.bias = bias; a.coef = coef; a.residual = residual; a.out = out; a.out_act = out_act;
+  a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = k == 3 ? dilation : 1; a.act = act;
+  a.D = D; a.kd = k;
+  a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
+  return conv_bx3_dispatch(a, k, ipdm_stream(stream));
+}
+
+extern "C" int ipdm_conv2d_bx3_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
+                                   const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
+                                   int Cout, int H, int W, int k, int dilation, void* stream) {
+  IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (k == 1 || k == 3) && dilation >= 1);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && wq && (out || out_act) && x != out && x != out_act);
+  if (k == 3 && dilation > 4) return IPDM_EUNSUPPORTED;
+  ConvArgs a;
+  a.x = x; a.wt = (const float*)wq; a.bias = bias; a.coef = coef; a.residual = residual; a.out = out; a.out_act = out_act;
+  a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = k == 3 ? dilation : 1; a.act = act;
+  a.D = 1; a.kd = 1;
+  a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
+  return conv_bx3_dispatch(a, k, ipdm_stream(stream));
+}

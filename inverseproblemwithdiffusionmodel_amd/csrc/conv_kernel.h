@@ -396,6 +396,8 @@ int conv_cfg_32x128s(const ConvArgs& a, int ks, hipStream_t s);    // <1,1,1,4,1
 int conv_cfg_64x128s(const ConvArgs& a, int ks, hipStream_t s);    // <1,2,2,2,16,4>
 int conv_cfg_128x128s(const ConvArgs& a, int ks, hipStream_t s);   // <2,2,2,2,16,4>
 
+unsigned long long* conv_debug_stamps();   // conv.hip: buffer set by ipdm_debug_set_stamp_buffer (NULL = off)
+
 // Winograd F(2x2,3x3) path (conv_wino.hip)
 bool wino_ok(const ConvArgs& a, int ks);
 int conv_wino_launch(ConvArgs a, hipStream_t s);

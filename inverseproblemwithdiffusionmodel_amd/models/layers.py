@@ -50,7 +50,7 @@ class Conv(nn.Module):
     def packed(self):
         v = (self.weight._version, self.weight.data_ptr())
         if self._packed is None or self._packed[0] != v:
-            self._packed = (v, ops.conv_pack_weight(self.weight.data))
+            self._packed = (v, ops.conv_weight(self.weight.data))
         return self._packed[1]
 
     def forward(self, x, residual=None):

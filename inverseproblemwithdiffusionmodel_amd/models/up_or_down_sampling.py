@@ -90,5 +90,5 @@ class Conv2d(nn.Module):
         if self.down:
             return conv_downsample_2d(x, self.weight, k=self.resample_kernel)
         if self._packed is None or self._packed[0] != self.weight._version:
-            self._packed = (self.weight._version, ops.conv_pack_weight(self.weight.data))
+            self._packed = (self.weight._version, ops.conv_weight(self.weight.data))
         return ops.conv2d(x, self._packed[1], self.bias.data if self.use_bias else None)

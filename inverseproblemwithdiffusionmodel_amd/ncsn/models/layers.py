@@ -54,7 +54,7 @@ def _act_code(act):
 
 class Conv2d(nn.Module):
     """stride-1 'same' convolution, kernel 1 or 3, optional dilation; weight in the reference's layout
-    [Cout, Cin, k, k] (what checkpoints carry), repacked once to [k*k, Cin, Cout] for the MFMA kernel."""
+    [Cout, Cin, k, k] (what checkpoints carry), repacked once for the selected kernel family (ops.conv_weight)."""
 
     def __init__(self, in_planes, out_planes, kernel_size=3, dilation=1, bias=True, ndim=2):
         super().__init__()
@@ -80,13 +80,13 @@ class Conv2d(nn.Module):
     def packed(self):
         v = (self.weight._version, self.weight.data_ptr())
         if self._packed is None or self._packed_version != v:
-            self._packed = ops.conv_pack_weight(self.weight.data)
+            self._packed = ops.conv_weight(self.weight.data)
             self._packed_version = v
         return self._packed
 
     def forward(self, x, coef=None, act=ops.ACT_NONE, residual=None, out=None, act_out=ops.ACT_NONE, raw=True):
         bias = None if self.bias is None else self.bias.data
-        if (USE_WINOGRAD and self.ndim == 2 and self.kernel_size == 3 and coef is None and act == ops.ACT_NONE
+        if (USE_WINOGRAD and ops.CONV_IMPL == "f32" and self.ndim == 2 and self.kernel_size == 3 and coef is None and act == ops.ACT_NONE
                 and out is None
                 and ops.conv_wino_supported(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation)):
             return ops.conv2d_wino(x, self.packed_wino(), bias, residual, act_out=act_out, raw=raw,

@@ -31,9 +31,9 @@ class _TemporalConv(nn.Module):
         v = (self.weight._version, self.weight.data_ptr())
         if self._packed is None or self._packed[0] != v:
             w = self.weight.data[:, :, 0, 0, :]                              # [a, b, 4]
-            # gathered channel index = ci*4 + k ; packed 1x1 layout [1][4*Cin][Cout]
-            wt = (w.permute(0, 2, 1) if self.transposed else w.permute(1, 2, 0)).reshape(1, self.in_ch * 4, self.out_ch)
-            self._packed = (v, wt.contiguous())
+            # gathered channel index = ci*4 + k : an ordinary 1x1 kernel [Cout][4*Cin][1][1]
+            w1 = (w.permute(1, 0, 2) if self.transposed else w).reshape(self.out_ch, self.in_ch * 4, 1, 1)
+            self._packed = (v, ops.conv_weight(w1.contiguous()))
         return self._packed[1]
 
     def forward(self, x):

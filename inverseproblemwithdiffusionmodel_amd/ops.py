@@ -3,6 +3,8 @@ PyTorch-ROCm (plumbing), all arithmetic happens in the hand-written HIP kernels 
 
 Every function requires GPU tensors and raises otherwise -- there is no CPU path.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -349,6 +351,8 @@ def conv2d_wino(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dila
 
 def conv3d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, act_out=ACT_NONE, raw=True):
     """x [B,Cin,D,H,W]; wt packed [27 or 1, Cin, Cout]; same fused input/output options as conv2d"""
+    if isinstance(wt, PackedBx3):
+        return conv_bx3(x, wt, bias, coef, act, residual, dilation, act_out=act_out, raw=raw)
     x = _gpu(x, torch.float32, "x")
     B, Cin, D, H, W = x.shape
     kk, Cin_w, Cout = wt.shape
@@ -393,6 +397,10 @@ def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1,
     Output side: bias, residual add; act_out != NONE additionally returns the activated copy act_out(result)
     (raw=False: ONLY the activated copy is produced).  Returns out, or (out, out_act) when act_out is set
     (out is None when raw=False)."""
+    if isinstance(wt, PackedBx3):
+        if pool2:
+            raise _lib.IpdmUnsupported("conv2d: pool2 epilogue is not fused")
+        return conv_bx3(x, wt, bias, coef, act, residual, dilation, out=out, act_out=act_out, raw=raw)
     x = _gpu(x, torch.float32, "x")
     B, Cin, H, W = x.shape
     kk, Cin_w, Cout = wt.shape
@@ -416,4 +424,82 @@ def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1,
     if CONV_TRACE is not None:
         e1.record()
         CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, dil=dilation, e0=e0, e1=e1))
+    return (out, out_act) if want_act else out
+
+
+# ---- convolution on the bf16 matrix cores (exact three-way split) ---------------------------------------------
+# Which kernel family the modules use (conv_weight()):
+#   "bx3" (default): fp32-faithful split-bf16 kernels (conv_bx3.hip) -- 2.67x the fp32 MFMA rate
+#   "f32":           the fp32-MFMA direct kernel + fp32 Winograd (conv.hip / conv_wino.hip)
+CONV_IMPL = os.environ.get("IPDM_CONV_IMPL", "bx3")
+if CONV_IMPL not in ("bx3", "f32"):
+    raise ValueError(f"IPDM_CONV_IMPL={CONV_IMPL!r}: expected 'bx3' or 'f32'")
+
+
+def conv_weight(w):
+    """pack a convolution weight for the selected kernel family; pass the result to conv2d / conv3d"""
+    return conv_bx3_weight(w) if CONV_IMPL == "bx3" else conv_pack_weight(w)
+
+
+class PackedBx3:
+    """weights split into three bf16 pieces and laid out as MFMA A-fragments (ipdm_conv_bx3_pack_weight)"""
+    __slots__ = ("blob", "Cout", "Cin", "kk")
+
+    def __init__(self, blob, Cout, Cin, kk):
+        self.blob, self.Cout, self.Cin, self.kk = blob, Cout, Cin, kk
+
+
+def conv_bx3_weight(w):
+    """[Cout, Cin, k, k] (k = 1 or 3) or [Cout, Cin, 3, 3, 3] / [Cout, Cin, 1, 1, 1] -> PackedBx3"""
+    w = _gpu(w, torch.float32, "weight")
+    Cout, Cin = w.shape[:2]
+    kk = 1
+    for n in w.shape[2:]:
+        kk *= int(n)
+    if w.dim() == 5:
+        if kk not in (1, 27):
+            raise ValueError("3-D kernels must be 1x1x1 or 3x3x3")
+        k = 27 if kk == 27 else 1
+    else:
+        k = {1: 1, 9: 3}[kk]
+    nbytes = _lib.lib.ipdm_conv_bx3_weight_bytes(Cout, Cin, k)
+    blob = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    call("ipdm_conv_bx3_pack_weight", _ptr(w), _ptr(blob), Cout, Cin, k, _stream())
+    return PackedBx3(blob, Cout, Cin, kk)
+
+
+def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, out=None, act_out=ACT_NONE, raw=True):
+    """2-D ([B,Cin,H,W]) or 3-D ([B,Cin,D,H,W]) convolution, same options / return convention as conv2d / conv3d"""
+    x = _gpu(x, torch.float32, "x")
+    if wq.Cin != x.shape[1]:
+        raise ValueError(f"conv_bx3: weight Cin {wq.Cin} != input Cin {x.shape[1]}")
+    vol = x.dim() == 5
+    k = {1: 1, 9: 3, 27: 3}[wq.kk]
+    if (wq.kk == 27) != (vol and k == 3):
+        raise ValueError("conv_bx3: kernel / input rank mismatch")
+    want_act = act_out != ACT_NONE
+    if not raw and not want_act:
+        raise ValueError("conv_bx3: raw=False needs act_out")
+    shape = (x.shape[0], wq.Cout) + tuple(x.shape[2:])
+    if raw:
+        out = torch.empty(shape, dtype=torch.float32, device=x.device) if out is None else out
+    else:
+        out = None
+    out_act = torch.empty(shape, dtype=torch.float32, device=x.device) if want_act else None
+    if CONV_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    if vol:
+        B, Cin, D, H, W = x.shape
+        call("ipdm_conv3d_bx3_f32", _ptr(x), _ptr(wq.blob), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
+             _ptr(out_act), act_out, B, Cin, wq.Cout, D, H, W, k, dilation, _stream())
+    else:
+        B, Cin, H, W = x.shape
+        D = 1
+        call("ipdm_conv2d_bx3_f32", _ptr(x), _ptr(wq.blob), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
+             _ptr(out_act), act_out, B, Cin, wq.Cout, H, W, k, dilation, _stream())
+    if CONV_TRACE is not None:
+        e1.record()
+        CONV_TRACE.append(dict(B=B * D, Cin=Cin, Cout=wq.Cout, H=H, W=W, k=k, dil=dilation, bx3=True,
+                               taps3d=wq.kk if vol else None, e0=e0, e1=e1))
     return (out, out_act) if want_act else out

@@ -13,6 +13,7 @@ B = int(os.environ.get("BENCH_B", 28))
 ONLY = os.environ.get("BENCH_ONLY")          # e.g. "0,1,2": indices into SHAPES
 NO_MIOPEN = os.environ.get("BENCH_NO_MIOPEN") == "1"
 WINO = os.environ.get("BENCH_WINO") == "1"     # Winograd F(2x2,3x3) path where eligible
+BX3 = os.environ.get("BENCH_BX3") == "1"       # bf16x3 split kernel (fp32-faithful on the bf16 matrix cores)
 FUSED = os.environ.get("BENCH_FUSED") == "1"   # ELU + InstanceNorm++ coefficients on the input, residual on the output
 SHAPES = [  # (count per forward, Cin, Cout, H, dil)
     (18, 128, 128, 128, 1), (9, 128, 128, 64, 1), (8, 256, 256, 64, 1), (17, 256, 256, 32, 1),
@@ -43,7 +44,15 @@ for idx, (cnt, ci, co, hw, dil) in enumerate(SHAPES):
     out = torch.empty(B, co, hw, hw, device="cuda")
     flop = 2.0 * B * hw * hw * ci * co * 9
     t_m = 1e9 if NO_MIOPEN else timeit(lambda: F.conv2d(x, w, bias, padding=dil, dilation=dil))
-    if WINO and ops.conv_wino_supported(ci, co, hw, hw, dil):
+    if BX3:
+        wq = ops.conv_bx3_weight(w)
+        t_o = timeit(lambda: ops.conv_bx3(x, wq, bias, dilation=dil, out=out))
+        x64, w64 = x[:2].double(), w.double()
+        ref64 = F.conv2d(x64, w64, bias.double(), padding=dil, dilation=dil)
+        e_bx3 = ((ops.conv_bx3(x[:2].contiguous(), wq, bias, dilation=dil).double() - ref64).abs().max() / ref64.abs().max()).item()
+        e_f32 = ((ops.conv2d(x[:2].contiguous(), wt, bias, dilation=dil).double() - ref64).abs().max() / ref64.abs().max()).item()
+        print(f"      rel-to-max error vs float64: bx3 {e_bx3:.2e}   fp32 MFMA {e_f32:.2e}")
+    elif WINO and ops.conv_wino_supported(ci, co, hw, hw, dil):
         U = ops.conv_wino_weight(w)
         t_o = timeit(lambda: ops.conv2d_wino(x, U, bias, dilation=dil))
         out = ops.conv2d_wino(x, U, bias, dilation=dil)

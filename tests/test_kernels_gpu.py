@@ -385,3 +385,85 @@ def test_conv2d_winograd(ops, B, Cin, Cout, H, W, res, dil):
     err = (raw.cpu().double() - want).abs().max()
     assert err < 4e-5 * max(1.0, float(want.abs().max())), float(err)
     assert (act.cpu().double() - F.elu(want)).abs().max() < 4e-5 * max(1.0, float(want.abs().max()))
+
+
+# ---- split-bf16 ("bf16x3") convolution: the same cases, held to a TIGHTER float64-referenced bound -------------
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,dil,norm,actname,res", CONV_CASES + [
+    (3, 32, 96, 40, 70, 3, 1, False, "none", True),          # several pixel tiles, ragged edges, 3 co-tiles of 32
+    (2, 48, 64, 16, 16, 3, 4, False, "none", False),         # PW = 16 tiles with dilation 4
+    (2, 20, 33, 9, 16, 1, 1, True, "elu", True),             # 1x1, ragged channels, fused norm + activation
+])
+def test_conv_bx3(ops, B, Cin, Cout, H, W, k, dil, norm, actname, res):
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=gen)
+    resid = torch.randn(B, Cout, H, W, generator=gen) if res else None
+    p = {"alpha": 1 + 0.1 * torch.randn(Cin, generator=gen), "gamma": 1 + 0.1 * torch.randn(Cin, generator=gen),
+         "beta": 0.1 * torch.randn(Cin, generator=gen)}
+    fn = {"none": lambda t: t, "elu": F.elu, "relu": F.relu}[actname]
+    h = scorenet.instance_norm_plus(x.double(), {a: b.double() for a, b in p.items()}) if norm else x.double()
+    want = F.conv2d(fn(h), w.double(), bias.double(), padding=(k // 2) * dil, dilation=dil)
+    if res:
+        want = want + resid.double()
+    xd = x.cuda()
+    coef = ops.instnorm_plus_coef(xd, p["alpha"].cuda(), p["gamma"].cuda(), p["beta"].cuda()) if norm else None
+    wq = ops.conv_bx3_weight(w.cuda())
+    got = ops.conv_bx3(xd, wq, bias.cuda(), coef, ops.ACT_CODES[actname], None if resid is None else resid.cuda(), dil)
+    err = (got.cpu().double() - want).abs().max()
+    # six-term split: the dropped products are < 2^-26 of |w x|, i.e. below the rounding of the fp32 accumulation
+    # itself; the fused norm/activation prologue (fp32) dominates when present
+    tol = (2e-5 if norm or actname != "none" else 4e-6) * max(1.0, float(want.abs().max()))
+    assert err < tol, float(err)
+    # the modules' dispatching entry (ops.conv2d on a PackedBx3) is the same launch
+    got2 = ops.conv2d(xd, wq, bias.cuda(), coef, ops.ACT_CODES[actname], None if resid is None else resid.cuda(), dil)
+    assert torch.equal(got, got2)
+
+
+def test_conv_bx3_exactness_and_layout(ops):
+    """a channel permutation with full-significand inputs must come back BIT-exact: the three bf16 pieces carry all
+    24 significand bits and the accumulator map is not transposed"""
+    Cin = Cout = 64
+    gen = torch.Generator().manual_seed(16)
+    x = (torch.randn(2, Cin, 8, 32, generator=gen) * 1000.0)
+    x[0, 0, 0, :4] = torch.tensor([1.0 + 2.0 ** -23, -(2.0 - 2.0 ** -22), 3.0e-30, 16777215.0])
+    w = torch.zeros(Cout, Cin, 3, 3)
+    for c in range(Cout):
+        w[c, (c * 7 + 3) % Cin, 1, 1] = 1.0
+    got = ops.conv_bx3(x.cuda(), ops.conv_bx3_weight(w.cuda())).cpu()
+    assert torch.equal(got, x[:, [(c * 7 + 3) % Cin for c in range(Cout)]])
+    # weights with full significands too: one tap, exact power-of-two input
+    w2 = torch.zeros(32, 16, 1, 1)
+    vals = torch.randn(32, generator=gen)
+    w2[torch.arange(32), torch.arange(32) % 16, 0, 0] = vals
+    x2 = torch.zeros(1, 16, 4, 32)
+    x2[0, :, :, :] = 0.5
+    got2 = ops.conv_bx3(x2.cuda(), ops.conv_bx3_weight(w2.cuda())).cpu()
+    assert torch.equal(got2[0, :, 0, 0], vals * 0.5)
+
+
+def test_conv_bx3_activated_second_output(ops):
+    gen = torch.Generator().manual_seed(14)
+    x = torch.randn(2, 64, 16, 32, generator=gen)
+    w = torch.randn(64, 64, 3, 3, generator=gen) / 24
+    resid = torch.randn(2, 64, 16, 32, generator=gen)
+    wq = ops.conv_bx3_weight(w.cuda())
+    want = F.conv2d(x.double(), w.double(), padding=1) + resid.double()
+    raw, act = ops.conv_bx3(x.cuda(), wq, residual=resid.cuda(), act_out=ops.ACT_ELU)
+    assert (raw.cpu().double() - want).abs().max() < 4e-6
+    assert (act.cpu().double() - F.elu(want)).abs().max() < 4e-6
+    none, act2 = ops.conv_bx3(x.cuda(), wq, residual=resid.cuda(), act_out=ops.ACT_ELU, raw=False)
+    assert none is None and torch.equal(act2, act)
+
+
+@pytest.mark.parametrize("dil,Cin,Cout,D,Hh,Ww", [(1, 8, 16, 8, 8, 24), (2, 16, 32, 8, 8, 12), (4, 32, 32, 8, 8, 24),
+                                                  (1, 1, 8, 5, 6, 7), (2, 8, 1, 4, 8, 24), (1, 128, 128, 8, 8, 24)])
+def test_conv_bx3_3d(ops, dil, Cin, Cout, D, Hh, Ww):
+    gen = torch.Generator().manual_seed(20)
+    x = torch.randn(3, Cin, D, Hh, Ww, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (Cin * 27) ** 0.5
+    b = torch.randn(Cout, generator=gen)
+    r = torch.randn(3, Cout, D, Hh, Ww, generator=gen)
+    want = F.conv3d(x.double(), w.double(), b.double(), padding=dil, dilation=dil) + r.double()
+    got = ops.conv3d(x.cuda(), ops.conv_bx3_weight(w.cuda()), b.cuda(), residual=r.cuda(), dilation=dil)
+    assert (got.cpu().double() - want).abs().max() < 4e-6 * max(1.0, float(want.abs().max()))
