@@ -241,6 +241,16 @@ int ipdm_conv3d_bx3_f32(const float* x, const void* packed, const float* bias, c
                         const float* residual, float* out, float* out_act, int act_out,
                         int B, int Cin, int Cout, int D, int H, int W, int k, int dilation, void* stream);
 
+/* Winograd F(2x2,3x3) with split-bf16 operands (3x3, Cin % 16 == 0, Cout % 64 == 0, see ..._supported): the same
+ * call sites and output options as ipdm_conv2d_wino_f32; weights transformed, split and laid out once per layer into
+ * a blob of ipdm_conv_wino_bx3_weight_bytes(Cout, Cin) bytes. */
+int64_t ipdm_conv_wino_bx3_weight_bytes(int Cout, int Cin);
+int ipdm_conv_wino_bx3_pack_weight(const float* w /* [Cout][Cin][3][3] */, void* U, int Cout, int Cin, void* stream);
+int ipdm_conv2d_wino_bx3_supported(int Cin, int Cout, int H, int W, int dilation);
+int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
+                             float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

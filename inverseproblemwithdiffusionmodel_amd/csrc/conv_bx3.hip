@@ -25,8 +25,6 @@
 
 namespace ipdm_conv {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS>
 struct BxCfg {
   static constexpr int TAPS = KS * KS;
@@ -44,19 +42,6 @@ struct BxCfg {
   static constexpr int ITEMS = (2 * PHP * PWP + 255) / 256;  // (pixel, 8-channel group) items per thread
   static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE * 16;
 };
-
-__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 hi = (__bf16)v[i];
-    const float r1 = v[i] - (float)hi;
-    const __bf16 mi = (__bf16)r1;
-    const float r2 = r1 - (float)mi;
-    h[i] = hi;
-    m[i] = mi;
-    l[i] = (__bf16)r2;
-  }
-}
 
 template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS, bool FAST>
 __global__ __launch_bounds__(256, (NCT * NPT <= 2 ? 4 : 2)) void conv_bx3_kernel(ConvArgs a) {

@@ -8,6 +8,22 @@
 namespace ipdm_conv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// exact three-way split of eight fp32 values into bf16 pieces: v = h + m + l (8 + 8 + 8 significand bits; both
+// residual subtractions are exact in fp32)
+__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 hi = (__bf16)v[i];
+    const float r1 = v[i] - (float)hi;
+    const __bf16 mi = (__bf16)r1;
+    const float r2 = r1 - (float)mi;
+    h[i] = hi;
+    m[i] = mi;
+    l[i] = (__bf16)r2;
+  }
+}
 
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{}).
 // Every register-array index below is a constant expression, so nothing is ever demoted to scratch.
@@ -402,5 +418,10 @@ unsigned long long* conv_debug_stamps();   // conv.hip: buffer set by ipdm_debug
 bool wino_ok(const ConvArgs& a, int ks);
 int conv_wino_launch(ConvArgs a, hipStream_t s);
 int conv_wino_weights(const float* w, float* U, int Cout, int Cin, hipStream_t s);
+
+// Winograd F(2x2,3x3) on the bf16 matrix cores with split operands (conv_wino_bx3.hip)
+bool wino_bx3_ok(const ConvArgs& a, int ks);
+int conv_wino_bx3_launch(ConvArgs a, hipStream_t s);
+int conv_wino_bx3_weights(const float* w, void* U, int Cout, int Cin, hipStream_t s);
 
 }  // namespace ipdm_conv

@@ -1,0 +1,493 @@
+// Winograd F(2x2, 3x3) convolution on the bf16 matrix cores with exactly split fp32 operands.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 2x2 output tile, 4x4 input tile d, 3x3 filter g
+// The 16 position-wise channel contractions  M_p[co, tile] = sum_ci U_p[co,ci] V_p[ci,tile]  run as in conv_bx3.hip:
+// U and V are each split into three bf16 pieces and every 32x32x16 product is six v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation (fp32-faithful, see conv_bx3.hip).  Winograd cuts the multiply-adds 2.25x, the split costs 6 bf16
+// MFMAs at 16x the fp32 MFMA rate: 6x fewer matrix-core cycles than the direct fp32 kernel.  On MI355X the dense
+// bf16 loop is power-limited, so fewer MFMAs per output is what buys time.
+//
+// Workgroup = 64 output channels x 64 tiles (4 tile rows x 16 tiles = 8 x 32 output pixels) of one image, 512 threads.
+// Wave w owns positions 2w and 2w+1 for ALL 64 channels x 64 tiles (2 positions x 2 channel tiles x 2 tile groups
+// = 128 accumulator registers), so both of its operands are private to it:
+//   A (U fragments): pre-split and laid out by ipdm_conv_wino_bx3_pack_weight as [pos][ci/16][co/32][piece][lane]
+//        16-byte units; global -> VGPR directly, prefetched one position ahead, used for two tile groups.
+//   B (V = B^T d B): the 4x4 patches go global -> regs (buffer loads, hardware zero padding), are transformed in fp32
+//        and stored to LDS as fp32 Vs[pos][ci 16][tile 64] (conflict-free 4-byte stores, lane <-> tile); the owning
+//        wave reads its 8 channels per lane back and splits them in registers right before the MFMAs.
+// Two 64 KiB LDS stages, one barrier per 16-channel chunk.  Epilogue: the accumulators meet through LDS
+// (M[pos][co 32][tile 64], one channel tile per round), every thread gathers the 16 positions of its (co, tile)
+// pairs, applies A^T M A, bias / residual / activation and stores float2 rows.
+//
+// Eligible: 3x3, Cin % 16 == 0, Cout % 64 == 0, no fused input normalisation / activation; wide images (W >= 32,
+// dilation 1) or the linear-tile-space variant for small / dilated images (polyphase, as conv_wino.hip).
+#include "conv_kernel.h"
+
+namespace ipdm_conv {
+
+namespace {
+
+constexpr int X_KC = 16;                 // input channels per chunk (one bf16 MFMA k-step)
+constexpr int X_CO = 64;
+constexpr int X_TX = 16, X_TY = 4;
+constexpr int X_TILES = X_TX * X_TY;     // 64
+constexpr int X_V_ELEMS = 16 * X_KC * X_TILES;                   // 16384 floats per stage
+// wide images: the raw input region of a chunk ((2*TY+2) x (2*TX+2) pixels x 16 channels) is brought into LDS by
+// LDS-DMA (buffer_load ... lds: no VGPRs, hardware zero padding) and the 4x4 patches are read from there
+constexpr int X_RR = 2 * X_TY + 2, X_RC = 2 * X_TX + 2;          // 10 x 34
+constexpr int X_RCH = 384;                                       // floats per channel (6 wave-instructions of 64 lanes)
+constexpr int X_R_ELEMS = X_KC * X_RCH;
+constexpr size_t X_LDS_BYTES = (2 * (size_t)X_V_ELEMS + X_R_ELEMS) * sizeof(float);   // 128 KiB + 24 KiB
+
+// U[p = a*4+b][co][ci] = sum_ij G[a][i] g[co][ci][i][j] G[b][j], split into three bf16 pieces, stored as MFMA
+// A fragments: [p][cc = ci/16][ct = co/32][piece][h][r][8]  (lane (r, h) holds ci = 16cc + 8h .. +7 of co = 32ct + r)
+__global__ __launch_bounds__(256) void wino_bx3_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                              int Cout, int Cin, int n_cc, int n_ct) {
+  const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+  const int64_t total = (int64_t)16 * n_cc * n_ct * 512;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int q = (int)(i & 7), r = (int)((i >> 3) & 31), h = (int)((i >> 8) & 1);
+    const int64_t rest = i >> 9;
+    const int ct = (int)(rest % n_ct);
+    const int cc = (int)((rest / n_ct) % n_cc);
+    const int p = (int)(rest / ((int64_t)n_ct * n_cc));
+    const int co = ct * 32 + r, ci = cc * 16 + 8 * h + q;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) {
+      const float* g = w + ((size_t)co * Cin + ci) * 9;
+      const int a = p >> 2, b = p & 3;
+      float t[3];
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) t[jj] = G[a][0] * g[jj] + G[a][1] * g[3 + jj] + G[a][2] * g[6 + jj];
+      v = t[0] * G[b][0] + t[1] * G[b][1] + t[2] * G[b][2];
+    }
+    const __bf16 hi = (__bf16)v;
+    const float r1 = v - (float)hi;
+    const __bf16 mi = (__bf16)r1;
+    const __bf16 lo = (__bf16)(r1 - (float)mi);
+    const int64_t base = rest * 3 * 512 + h * 256 + r * 8 + q;
+    out[base] = __builtin_bit_cast(unsigned short, hi);
+    out[base + 512] = __builtin_bit_cast(unsigned short, mi);
+    out[base + 1024] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+
+template <bool SMALL>
+__global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
+  extern __shared__ __align__(16) float lds[];
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  if (a.dbg) t0 = __builtin_amdgcn_s_memtime();
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, slot = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int co_tile = bid % a.co_tiles;
+  int t = bid / a.co_tiles;
+  const int tx = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int ty = t % a.tiles_y;
+  const int b = t / a.tiles_y;
+  const int co0 = co_tile * X_CO;
+  const int y0 = ty * (2 * X_TY), x0 = tx * (2 * X_TX);
+  // SMALL: 64 consecutive tiles of the image's linear tile space; a dilation-d convolution is d*d undilated ones on
+  // the d-subsampled images: tile t = ((sy*d + sx)*THS + tyy)*TWS + txx covers output (d*(2*tyy+i)+sy, d*(2*txx+j)+sx)
+  const int d = a.dil;
+  const int TWS = SMALL ? a.W / (2 * d) : 0, THS = SMALL ? a.H / (2 * d) : 0;
+  const int tile0 = SMALL ? tx * X_TILES : 0;
+  auto tile_origin = [&](int tl, int& py, int& px) {
+    const int txx = tl % TWS;
+    int r = tl / TWS;
+    const int tyy = r % THS;
+    r /= THS;
+    py = d * (2 * tyy) + r / d;
+    px = d * (2 * txx) + r % d;
+  };
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, j = lane & 31;
+  const int HW = a.H * a.W;
+  const int n_cc = a.Cin / X_KC, n_ct = a.Cout / 32;
+  const int p0 = 2 * wave;                                   // this wave's positions: p0, p0 + 1
+
+  // ---- staging geometry: this thread transforms tile `mytile` of channels 2*wave, 2*wave+1 of every chunk ----
+  const int mytile = tid & 63;
+  int row_off[4], col_off[4];                                // byte offsets; 0x20000000 marks padding
+  {
+    int my_py = 0, my_px = 0;
+    bool my_tile_ok = true;
+    if constexpr (SMALL) {
+      my_tile_ok = tile0 + mytile < THS * TWS * d * d;
+      tile_origin(my_tile_ok ? tile0 + mytile : 0, my_py, my_px);
+    }
+    const int tyl = mytile / X_TX, txl = mytile % X_TX;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int gy = SMALL ? my_py + d * (e - 1) : y0 + 2 * tyl - 1 + e;
+      const int gx = SMALL ? my_px + d * (e - 1) : x0 + 2 * txl - 1 + e;
+      const bool oky = my_tile_ok && gy >= 0 && gy < a.H, okx = gx >= 0 && gx < a.W;
+      row_off[e] = oky ? gy * a.W * 4 : 0x20000000;          // out-of-range sum -> the buffer load returns 0
+      col_off[e] = okx ? gx * 4 : 0x20000000;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((size_t)a.B * a.Cin * HW * 4), 0x00020000);
+
+  float dreg[16];
+  auto load_patch = [&](int ci) {                            // ci: absolute input channel (wave-uniform)
+    const int soff = (int)(((size_t)b * a.Cin + ci) * HW * 4);
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      dreg[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, row_off[e / 4] + col_off[e % 4], soff, 0));
+  };
+  // B^T d B of the patch in dreg -> Vs[pos][kc][mytile] of stage st
+  auto store_patch = [&](float* st, int kc) {
+    const float(&dd)[16] = dreg;
+    float tmp[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      tmp[0 * 4 + c] = dd[0 * 4 + c] - dd[2 * 4 + c];
+      tmp[1 * 4 + c] = dd[1 * 4 + c] + dd[2 * 4 + c];
+      tmp[2 * 4 + c] = dd[2 * 4 + c] - dd[1 * 4 + c];
+      tmp[3 * 4 + c] = dd[1 * 4 + c] - dd[3 * 4 + c];
+    }
+    float* vs = st + kc * X_TILES + mytile;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      vs[(r * 4 + 0) * X_KC * X_TILES] = tmp[r * 4 + 0] - tmp[r * 4 + 2];
+      vs[(r * 4 + 1) * X_KC * X_TILES] = tmp[r * 4 + 1] + tmp[r * 4 + 2];
+      vs[(r * 4 + 2) * X_KC * X_TILES] = tmp[r * 4 + 2] - tmp[r * 4 + 1];
+      vs[(r * 4 + 3) * X_KC * X_TILES] = tmp[r * 4 + 1] - tmp[r * 4 + 3];
+    }
+  };
+
+  // ---- wide images: raw region via LDS-DMA; wave w brings in channels 2w, 2w+1 (6 x 64 floats each) ----
+  float* const rs = lds + 2 * X_V_ELEMS;
+  int dma_off[6];
+  if constexpr (!SMALL) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int e = k * 64 + lane;
+      const int r = e / X_RC, c = e - r * X_RC;
+      const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+      const bool ok = e < X_RR * X_RC && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      dma_off[k] = ok ? (gy * a.W + gx) * 4 : 0x40000000;      // out of range -> the DMA writes 0
+    }
+  }
+  auto issue_dma = [&](int chunk) {
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl) {
+      const int kc = 2 * wave + cl;
+      const int soff = (int)(((size_t)b * a.Cin + chunk * X_KC + kc) * HW * 4);
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(rs + kc * X_RCH + k * 64), 4,
+                                                 dma_off[k], soff, 0, 0);
+    }
+  };
+  const int r_lane = (2 * (mytile / X_TX)) * X_RC + 2 * (mytile % X_TX);
+  auto read_patch = [&](int kc) {                              // 4x4 patch of channel kc (chunk-local) from the raw stage
+    const float* rp = rs + kc * X_RCH + r_lane;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float2 lo = *reinterpret_cast<const float2*>(rp + r * X_RC);
+      const float2 hi = *reinterpret_cast<const float2*>(rp + r * X_RC + 2);
+      dreg[r * 4 + 0] = lo.x; dreg[r * 4 + 1] = lo.y; dreg[r * 4 + 2] = hi.x; dreg[r * 4 + 3] = hi.y;
+    }
+  };
+
+  // ---- A fragments ----
+  const uint4* wq = reinterpret_cast<const uint4*>(a.wt);
+  const size_t pos_stride = (size_t)n_cc * n_ct * 192;
+  const int a_lane = (co_tile * 2) * 192 + lane;             // channel tile c adds 192
+  auto load_A = [&](bf16x8 (&fr)[2][3], int p, int cc) {
+    const uint4* base = wq + (size_t)p * pos_stride + (size_t)cc * n_ct * 192 + a_lane;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) fr[c][s] = __builtin_bit_cast(bf16x8, base[c * 192 + s * 64]);
+  };
+  // ---- B operand: 8 channels (8h .. 8h+7) of tile (tg*32 + j) at position p, fp32 ----
+  const int b_lane = (8 * h) * X_TILES + j;
+  auto load_B = [&](float (&raw)[8], const float* cur, int pi, int tg) {
+    const float* bp = cur + (p0 + pi) * (X_KC * X_TILES) + tg * 32 + b_lane;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) raw[q] = bp[q * X_TILES];
+  };
+
+  f32x16 acc[2][2][2];                                       // [position][channel tile][tile group]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i >> 2][(i >> 1) & 1][i & 1][r] = 0.f;
+
+  bf16x8 afr[2][2][3];
+  const int n_chunks = n_cc;
+  // prologue: stage 0 completely, and channel 2w of chunk 1 already in flight in dreg
+  load_A(afr[0], p0, 0);
+  if constexpr (SMALL) {
+    load_patch(2 * wave);
+    store_patch(lds, 2 * wave);
+    load_patch(2 * wave + 1);
+    store_patch(lds, 2 * wave + 1);
+    load_patch((n_chunks > 1 ? X_KC : 0) + 2 * wave);
+    __syncthreads();
+  } else {
+    issue_dma(0);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    read_patch(2 * wave);
+    store_patch(lds, 2 * wave);
+    read_patch(2 * wave + 1);
+    store_patch(lds, 2 * wave + 1);
+    __syncthreads();                                           // raw stage free again
+    issue_dma(n_chunks > 1 ? 1 : 0);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+  }
+  if (a.dbg) t1 = __builtin_amdgcn_s_memtime();
+
+  // Steady state, branch-free.  Per chunk a wave runs four steps (position, tile group) of 12 MFMAs each; the side
+  // work is dealt into the MFMA shadows with sched_group_barrier:
+  //   every step : the LDS reads of the NEXT step's B operand, then its three-way split (VALU)
+  //   step 0     : transform + store channel 2w of chunk c+1 (in flight since step 2 of chunk c-1), issue the loads
+  //                of channel 2w+1; issue the A fragments of position p0+1
+  //   step 2     : transform + store channel 2w+1 of chunk c+1, issue the loads of channel 2w of chunk c+2; issue
+  //                the A fragments of position p0 of chunk c+1
+  // (past the last chunk the channel index is clamped: redundant loads, stores into a stage nobody reads)
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    const float* cur = lds + (ch & 1) * X_V_ELEMS;
+    float* nxt = lds + ((ch + 1) & 1) * X_V_ELEMS;
+    const int ch1 = ch + 1 < n_chunks ? ch + 1 : n_chunks - 1;
+    const int ch2 = ch + 2 < n_chunks ? ch + 2 : n_chunks - 1;
+    bf16x8 bs[2][3];
+    float raw[8];
+    load_B(raw, cur, 0, 0);
+    split3(raw, bs[0][0], bs[0][1], bs[0][2]);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<4>([&](auto sc) {
+      constexpr int st = decltype(sc)::value;
+      constexpr int pi = st >> 1, tg = st & 1;
+      if constexpr (st < 3) load_B(raw, cur, (st + 1) >> 1, (st + 1) & 1);
+      if constexpr (SMALL) {
+        if constexpr (st == 0) {
+          store_patch(nxt, 2 * wave);
+          load_patch(ch1 * X_KC + 2 * wave + 1);
+          load_A(afr[1], p0 + 1, ch);
+        }
+        if constexpr (st == 2) {
+          store_patch(nxt, 2 * wave + 1);
+          load_patch(ch2 * X_KC + 2 * wave);
+          load_A(afr[0], p0, ch1);
+        }
+      } else {
+        // the raw stage holds chunk c+1: transform it in step 0, refill it with chunk c+2 from step 1 on (three
+        // steps for the DMA to land before the end-of-chunk barrier)
+        if constexpr (st == 0) {
+          read_patch(2 * wave);
+          store_patch(nxt, 2 * wave);
+          read_patch(2 * wave + 1);
+          store_patch(nxt, 2 * wave + 1);
+          load_A(afr[1], p0 + 1, ch);
+        }
+        if constexpr (st == 1) issue_dma(ch2);
+        if constexpr (st == 2) load_A(afr[0], p0, ch1);
+      }
+      if constexpr (st < 3) split3(raw, bs[(st + 1) & 1][0], bs[(st + 1) & 1][1], bs[(st + 1) & 1][2]);
+      const bf16x8 bh = bs[st & 1][0], bm = bs[st & 1][1], bl = bs[st & 1][2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        f32x16 v = acc[pi][c][tg];
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][2], bh, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bl, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][1], bm, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][1], bh, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bm, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bh, v, 0, 0, 0);
+        acc[pi][c][tg] = v;
+      }
+      if constexpr (st < 3) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);          // next step's LDS reads first
+      constexpr bool XFORM = SMALL ? (st == 0 || st == 2) : st == 0;
+      constexpr bool VMEM = SMALL ? (st == 0 || st == 2) : st < 3;
+      if constexpr (!SMALL && XFORM) __builtin_amdgcn_sched_group_barrier(0x100, 16, 0); // the patch reads
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x006, XFORM ? (SMALL ? 10 : 12) : 5, 0);  // VALU / SALU in its shadow
+        if constexpr (XFORM) __builtin_amdgcn_sched_group_barrier(0x200, SMALL ? 2 : 3, 0);   // patch stores
+        if constexpr (VMEM) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);          // patch / fragment loads, DMA
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!SMALL && st == 0) __syncthreads();        // everyone has read the raw stage
+    });
+    if constexpr (!SMALL) __builtin_amdgcn_s_waitcnt(0);       // the DMA of chunk c+2 has landed
+    __syncthreads();
+  }
+  if (a.dbg) t2 = __builtin_amdgcn_s_memtime();
+
+  // ---- epilogue: M -> LDS (one channel tile per round), gather 16 positions per (co, tile), A^T M A ----
+  const int tile = tid & 63;
+  const int cg = tid >> 6;                                   // channels 4*cg .. 4*cg+3 of the round's 32
+  int oy = y0 + 2 * (tile / X_TX), ox = x0 + 2 * (tile % X_TX);
+  bool out_ok = oy < a.H && ox < a.W;
+  if constexpr (SMALL) {
+    out_ok = tile0 + tile < THS * TWS * d * d;
+    tile_origin(out_ok ? tile0 + tile : 0, oy, ox);
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (c > 0) __syncthreads();                              // the previous round's reads are done
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+      for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int col = (r & 3) + 8 * (r >> 2) + 4 * h;
+          lds[((p0 + pi) * 32 + col) * X_TILES + tg * 32 + j] = acc[pi][c][tg][r];
+        }
+    __syncthreads();
+    if (out_ok) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cl = cg * 4 + i;
+        const int co = co0 + c * 32 + cl;
+        float m[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) m[p] = lds[(p * 32 + cl) * X_TILES + tile];
+        float tt[2][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          tt[0][q] = m[0 * 4 + q] + m[1 * 4 + q] + m[2 * 4 + q];
+          tt[1][q] = m[1 * 4 + q] - m[2 * 4 + q] - m[3 * 4 + q];
+        }
+        const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          float y0v = tt[ii][0] + tt[ii][1] + tt[ii][2] + bias;
+          float y1v = tt[ii][1] - tt[ii][2] - tt[ii][3] + bias;
+          const size_t o = ((size_t)b * a.Cout + co) * HW + (size_t)(oy + (SMALL ? d * ii : ii)) * a.W + ox;
+          if constexpr (SMALL) {
+            if (a.residual) {
+              y0v += a.residual[o];
+              y1v += a.residual[o + d];
+            }
+            if (a.out) {
+              a.out[o] = y0v;
+              a.out[o + d] = y1v;
+            }
+            if (a.out_act) {
+              a.out_act[o] = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
+              a.out_act[o + d] = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
+            }
+          } else {
+            if (a.residual) {
+              const float2 rr2 = *reinterpret_cast<const float2*>(a.residual + o);
+              y0v += rr2.x;
+              y1v += rr2.y;
+            }
+            if (a.out) *reinterpret_cast<float2*>(a.out + o) = make_float2(y0v, y1v);
+            if (a.out_act) {
+              const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
+              const float e1 = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
+              *reinterpret_cast<float2*>(a.out_act + o) = make_float2(e0, e1);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (a.dbg) {
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      unsigned long long* d4 = a.dbg + (size_t)blockIdx.x * 4;
+      d4[0] = t0; d4[1] = t1; d4[2] = t2; d4[3] = t3;
+    }
+  }
+}
+
+bool x_small(const ConvArgs& a) { return a.W < 32 || a.dil > 1; }
+
+}  // namespace
+
+bool wino_bx3_ok(const ConvArgs& a, int ks) {
+  if (!(ks == 3 && a.D == 1 && a.Cin % X_KC == 0 && a.Cout % X_CO == 0 && !a.coef && a.act == IPDM_ACT_NONE)) return false;
+  if (a.dil < 1 || a.dil > 4) return false;
+  if ((size_t)a.B * a.Cin * a.H * a.W * 4 >= 0x1fffffffull) return false;   // buffer offsets + padding marker < 2^30
+  if (x_small(a)) return a.H % (2 * a.dil) == 0 && a.W % (2 * a.dil) == 0 && (a.H * a.W) / 4 >= 32;
+  return a.H % 2 == 0 && a.W % 2 == 0 && a.H >= 8;
+}
+
+int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
+  const bool small = x_small(a);
+  if (small) {
+    a.tiles_x = ((a.H * a.W) / 4 + X_TILES - 1) / X_TILES;
+    a.tiles_y = 1;
+  } else {
+    a.tiles_x = (a.W + 2 * X_TX - 1) / (2 * X_TX);
+    a.tiles_y = (a.H + 2 * X_TY - 1) / (2 * X_TY);
+  }
+  a.co_tiles = a.Cout / X_CO;
+  const int64_t nblk = (int64_t)a.B * a.tiles_x * a.tiles_y * a.co_tiles;
+  if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  if (small) hipLaunchKernelGGL(conv_wino_bx3_kernel<true>, dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
+  else hipLaunchKernelGGL(conv_wino_bx3_kernel<false>, dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
+  return ipdm_launch_status();
+}
+
+int conv_wino_bx3_weights(const float* w, void* U, int Cout, int Cin, hipStream_t s) {
+  const int n_cc = (Cin + 15) / 16, n_ct = (Cout + 31) / 32;
+  const int64_t total = (int64_t)16 * n_cc * n_ct * 512;
+  hipLaunchKernelGGL(wino_bx3_weight_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, s, w, (unsigned short*)U, Cout,
+                     Cin, n_cc, n_ct);
+  return ipdm_launch_status();
+}
+
+}  // namespace ipdm_conv
+
+using namespace ipdm_conv;
+
+extern "C" int64_t ipdm_conv_wino_bx3_weight_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0) return -1;
+  return (int64_t)16 * ((Cin + 15) / 16) * ((Cout + 31) / 32) * 3072;
+}
+
+extern "C" int ipdm_conv_wino_bx3_pack_weight(const float* w, void* U, int Cout, int Cin, void* stream) {
+  IPDM_REQUIRE(w && U && Cout > 0 && Cin > 0);
+  return conv_wino_bx3_weights(w, U, Cout, Cin, ipdm_stream(stream));
+}
+
+extern "C" int ipdm_conv2d_wino_bx3_supported(int Cin, int Cout, int H, int W, int dilation) {
+  ConvArgs a;
+  a.coef = nullptr; a.act = IPDM_ACT_NONE; a.dil = dilation; a.D = 1; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.B = 1;
+  return wino_bx3_ok(a, 3) ? 1 : 0;
+}
+
+extern "C" int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const float* bias, const float* residual,
+                                        float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H, int W,
+                                        int dilation, void* stream) {
+  IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && dilation >= 1);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && U && (out || out_act) && x != out && x != out_act);
+  ConvArgs a;
+  a.x = x; a.wt = (const float*)U; a.bias = bias; a.coef = nullptr; a.residual = residual; a.out = out; a.out_act = out_act;
+  a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = dilation; a.act = IPDM_ACT_NONE;
+  a.D = 1; a.kd = 1; a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
+  if (!wino_bx3_ok(a, 3)) return IPDM_EUNSUPPORTED;
+  return conv_wino_bx3_launch(a, ipdm_stream(stream));
+}

@@ -77,6 +77,12 @@ class Conv2d(nn.Module):
             self._wino = (v, ops.conv_wino_weight(self.weight.data))
         return self._wino[1]
 
+    def packed_wino_bx3(self):
+        v = (self.weight._version, self.weight.data_ptr())
+        if self._wino is None or self._wino[0] != v:
+            self._wino = (v, ops.conv_wino_bx3_weight(self.weight.data))
+        return self._wino[1]
+
     def packed(self):
         v = (self.weight._version, self.weight.data_ptr())
         if self._packed is None or self._packed_version != v:
@@ -91,6 +97,11 @@ class Conv2d(nn.Module):
                 and ops.conv_wino_supported(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation)):
             return ops.conv2d_wino(x, self.packed_wino(), bias, residual, act_out=act_out, raw=raw,
                                    dilation=self.dilation)
+        if (USE_WINOGRAD and ops.CONV_IMPL == "bx3" and self.ndim == 2 and self.kernel_size == 3 and coef is None
+                and act == ops.ACT_NONE and out is None and ops.wino_bx3_pays(self.in_planes, self.out_planes, x.shape[2],
+                                                                              x.shape[3], self.dilation)):
+            return ops.conv2d_wino_bx3(x, self.packed_wino_bx3(), bias, residual, act_out=act_out, raw=raw,
+                                       dilation=self.dilation)
         if self.ndim == 3:
             return ops.conv3d(x, self.packed(), bias, coef, act, residual, self.dilation, act_out=act_out, raw=raw)
         return ops.conv2d(x, self.packed(), bias, coef, act, residual, self.dilation, out=out, act_out=act_out, raw=raw)

@@ -503,3 +503,46 @@ def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=
         CONV_TRACE.append(dict(B=B * D, Cin=Cin, Cout=wq.Cout, H=H, W=W, k=k, dil=dilation, bx3=True,
                                taps3d=wq.kk if vol else None, e0=e0, e1=e1))
     return (out, out_act) if want_act else out
+
+
+def conv_wino_bx3_weight(w):
+    """[Cout, Cin, 3, 3] -> Winograd-domain weights, split into bf16 pieces in MFMA fragment order (PackedBx3, kk=16)"""
+    w = _gpu(w, torch.float32, "weight")
+    Cout, Cin = w.shape[:2]
+    blob = torch.empty(_lib.lib.ipdm_conv_wino_bx3_weight_bytes(Cout, Cin), dtype=torch.uint8, device=w.device)
+    call("ipdm_conv_wino_bx3_pack_weight", _ptr(w), _ptr(blob), Cout, Cin, _stream())
+    return PackedBx3(blob, Cout, Cin, 16)
+
+
+def conv_wino_bx3_supported(Cin, Cout, H, W, dilation=1):
+    return bool(_lib.lib.ipdm_conv2d_wino_bx3_supported(Cin, Cout, H, W, dilation))
+
+
+def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dilation=1):
+    """3x3 convolution through the split-bf16 Winograd kernel (same output options as conv2d)"""
+    x = _gpu(x, torch.float32, "x")
+    B, Cin, H, W = x.shape
+    if U.kk != 16 or U.Cin != Cin:
+        raise ValueError("conv2d_wino_bx3: weight blob does not match the input")
+    Cout = U.Cout
+    want_act = act_out != ACT_NONE
+    out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device) if raw else None
+    out_act = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device) if want_act else None
+    if CONV_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("ipdm_conv2d_wino_bx3_f32", _ptr(x), _ptr(U.blob), _ptr(bias), _ptr(residual), _ptr(out), _ptr(out_act), act_out,
+         B, Cin, Cout, H, W, dilation, _stream())
+    if CONV_TRACE is not None:
+        e1.record()
+        CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, e0=e0, e1=e1))
+    return (out, out_act) if want_act else out
+
+
+def wino_bx3_pays(Cin, Cout, H, W, dilation=1):
+    """dispatch rule measured on MI355X (scripts/bench_conv.py): the split-bf16 Winograd kernel beats the direct
+    split-bf16 kernel wherever it is eligible, except on undilated images of 16 pixels or less across (a single
+    64-tile workgroup per image and channel tile leaves most of the chip idle)"""
+    if W <= 16 and dilation == 1:
+        return False
+    return conv_wino_bx3_supported(Cin, Cout, H, W, dilation)

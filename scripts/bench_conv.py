@@ -44,7 +44,15 @@ for idx, (cnt, ci, co, hw, dil) in enumerate(SHAPES):
     out = torch.empty(B, co, hw, hw, device="cuda")
     flop = 2.0 * B * hw * hw * ci * co * 9
     t_m = 1e9 if NO_MIOPEN else timeit(lambda: F.conv2d(x, w, bias, padding=dil, dilation=dil))
-    if BX3:
+    if BX3 and WINO and ops.conv_wino_bx3_supported(ci, co, hw, hw, dil):
+        Uq = ops.conv_wino_bx3_weight(w)
+        t_o = timeit(lambda: ops.conv2d_wino_bx3(x, Uq, bias, dilation=dil))
+        out = ops.conv2d_wino_bx3(x, Uq, bias, dilation=dil)
+        ref64 = F.conv2d(x[:2].double(), w.double(), bias.double(), padding=dil, dilation=dil)
+        e_w = ((ops.conv2d_wino_bx3(x[:2].contiguous(), Uq, bias, dilation=dil).double() - ref64).abs().max() / ref64.abs().max()).item()
+        e_f = ((ops.conv2d_wino(x[:2].contiguous(), ops.conv_wino_weight(w), bias, dilation=dil).double() - ref64).abs().max() / ref64.abs().max()).item() if ops.conv_wino_supported(ci, co, hw, hw, dil) else float("nan")
+        print(f"      rel-to-max error vs float64: wino-bx3 {e_w:.2e}   wino-fp32 {e_f:.2e}")
+    elif BX3:
         wq = ops.conv_bx3_weight(w)
         t_o = timeit(lambda: ops.conv_bx3(x, wq, bias, dilation=dil, out=out))
         x64, w64 = x[:2].double(), w.double()

@@ -467,3 +467,33 @@ def test_conv_bx3_3d(ops, dil, Cin, Cout, D, Hh, Ww):
     want = F.conv3d(x.double(), w.double(), b.double(), padding=dil, dilation=dil) + r.double()
     got = ops.conv3d(x.cuda(), ops.conv_bx3_weight(w.cuda()), b.cuda(), residual=r.cuda(), dilation=dil)
     assert (got.cpu().double() - want).abs().max() < 4e-6 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,res,dil", [
+    (2, 64, 64, 32, 32, True, 1), (1, 128, 128, 64, 64, False, 1), (3, 256, 256, 32, 32, True, 1),
+    (2, 16, 64, 10, 36, False, 1), (1, 128, 256, 128, 128, False, 1), (2, 32, 64, 40, 70, True, 1),   # ragged edges
+    (3, 64, 64, 16, 16, True, 1), (2, 64, 128, 16, 16, True, 2), (2, 128, 64, 16, 16, False, 4),      # small / dilated
+    (1, 16, 64, 24, 16, False, 2), (1, 16, 64, 32, 32, True, 2)])
+def test_conv2d_winograd_bx3(ops, B, Cin, Cout, H, W, res, dil):
+    """split-bf16 F(2x2,3x3) path (LDS-DMA raw stage on wide images, register path on small / dilated ones) vs a
+    float64 direct convolution"""
+    assert ops.conv_wino_bx3_supported(Cin, Cout, H, W, dil)
+    assert not ops.conv_wino_bx3_supported(Cin + 8, Cout, H, W, dil) and not ops.conv_wino_bx3_supported(Cin, Cout + 32, H, W, dil)
+    gen = torch.Generator().manual_seed(15)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    bias = torch.randn(Cout, generator=gen)
+    resid = torch.randn(B, Cout, H, W, generator=gen) if res else None
+    want = F.conv2d(x.double(), w.double(), bias.double(), padding=dil, dilation=dil)
+    if res:
+        want = want + resid.double()
+    U = ops.conv_wino_bx3_weight(w.cuda())
+    raw, act = ops.conv2d_wino_bx3(x.cuda(), U, bias.cuda(), None if resid is None else resid.cuda(), act_out=ops.ACT_ELU,
+                                   dilation=dil)
+    scale = max(1.0, float(want.abs().max()))
+    err = (raw.cpu().double() - want).abs().max()
+    assert err < 1e-5 * scale, float(err)          # Winograd transforms in fp32: a few ulp above the direct kernels
+    assert (act.cpu().double() - F.elu(want)).abs().max() < 1e-5 * scale
+    # repeated launches are bit-identical (no race between the DMA refill, the transform and the MFMA reads)
+    raw2 = ops.conv2d_wino_bx3(x.cuda(), U, bias.cuda(), None if resid is None else resid.cuda(), dilation=dil)
+    assert torch.equal(raw, raw2)
