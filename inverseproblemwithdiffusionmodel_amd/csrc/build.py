@@ -43,6 +43,7 @@ def build(force=False, verbose=False):
             if os.path.basename(src).startswith("conv"):
                 # the MFMA convolution is an fma chain by construction; let its prologue VALU math fuse too
                 flags[flags.index("-ffp-contract=off")] = "-ffp-contract=fast"
+            flags += os.environ.get("IPDM_EXTRA_HIPCC_FLAGS", "").split()     # diagnostic builds (e.g. -DIPDM_WBX3_TRACE)
             jobs.append([HIPCC, *flags, "-c", src, "-o", obj])
 
     def run(cmd):

@@ -83,8 +83,12 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, slot = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
-  const int co_tile = bid % a.co_tiles;
-  int t = bid / a.co_tiles;
+  // wide images: the channel tiles of one pixel tile are neighbours (they share the input region through L2);
+  // small images: channel-tile-major, so that an XCD works on ONE channel tile's Winograd weights (16 x Cin x 64 x 6
+  // bytes, 3 MiB at Cin = 512 -- eight of them would thrash the 4 MiB L2) across all images
+  const int n_px = nblk / a.co_tiles;
+  const int co_tile = SMALL ? bid / n_px : bid % a.co_tiles;
+  int t = SMALL ? bid % n_px : bid / a.co_tiles;
   const int tx = t % a.tiles_x;
   t /= a.tiles_x;
   const int ty = t % a.tiles_y;

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""step-level timeline of one chunk of the split-bf16 Winograd kernel (needs a build with -DIPDM_WBX3_TRACE)"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from inverseproblemwithdiffusionmodel_amd import ops, _lib
+B, ci, co, hw = 28, 128, 128, 128
+x = torch.randn(B, ci, hw, hw, device="cuda"); w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
+U = ops.conv_wino_bx3_weight(w)
+nblk = B * (hw // 8) * (hw // 32) * (co // 64)
+buf = torch.zeros(nblk * 4 + nblk * 64, dtype=torch.int64, device="cuda")
+for _ in range(3): ops.conv2d_wino_bx3(x, U)
+torch.cuda.synchronize()
+_lib.lib.ipdm_debug_set_stamp_buffer(_lib.P(buf.data_ptr()))
+ops.conv2d_wino_bx3(x, U); torch.cuda.synchronize()
+_lib.lib.ipdm_debug_set_stamp_buffer(_lib.P(0))
+t = buf.cpu()[nblk * 4:].view(nblk, 8, 8).double()
+names = ["B0 read+split", "step0 (xform)", "mid barrier", "step1 (dma)", "step2", "step3", "dma wait", "end barrier"]
+# stamp order in tr: 0 start, 1 after st0, 5 after mid barrier, 2 after st1, 3 after st2, 4 after st3, 6 after dma wait, 7 after barrier
+seq = [0, 1, 5, 2, 3, 4, 6, 7]
+d = torch.stack([t[:, :, seq[i + 1]] - t[:, :, seq[i]] for i in range(7)], dim=-1)   # [blk, wave, 7]
+med = d.median(dim=0).values
+print("median cycles per segment, per wave (rows = wave 0..7):")
+print("   " + "  ".join(f"{n:>14s}" for n in ["st0(+B0 split)", "mid barrier", "step1 (dma)", "step2", "step3", "dma wait", "end barrier"]))
+for wv in range(8):
+    print(f"w{wv} " + "  ".join(f"{med[wv, i]:14.0f}" for i in range(7)), f"  total {med[wv].sum():.0f}")
