@@ -229,7 +229,8 @@ def main():
             with open(pmc) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         n_bx3 = sum(1 for r in reps[0] if r.get("bx3"))
-        flops_bx3 = sum(r["flops"] for r in reps[0] if r.get("bx3"))
+        # bf16 MFMA FLOPs actually executed: six per fp32 multiply-add, 2.25x fewer on the Winograd launches
+        flops_bx3 = sum(r["flops"] / (2.25 if r.get("wino") else 1.0) for r in reps[0] if r.get("bx3"))
         common = {
             "traffic": traffic, "algorithmic_bytes_per_launch": bytes_alg, "launches_per_step": len(reps[0]),
             "avg_launch_ms": conv_ms / len(reps[0]), "algorithmic_flops_per_step": flops, "conv_ms_per_step": conv_ms,
@@ -241,11 +242,13 @@ def main():
             peak = PEAK_BF16_MFMA_TFLOPS / 6.0
             out["roofline"] = dict({
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "kernel": "conv_bx3_kernel<...> (fp32 convolution as 6 x v_mfma_f32_32x32x16_bf16 on exact bf16x3 "
-                          "operand splits, fp32 accumulate)",
+                "kernel": "conv_wino_bx3_kernel (Winograd F(2x2,3x3)) + conv_bx3_kernel<...> (direct): fp32 convolution as "
+                          "6 x v_mfma_f32_32x32x16_bf16 on exact bf16x3 operand splits, fp32 accumulate",
                 "achieved_note": "algorithmic fp32 FLOPs (2*MACs of the direct convolution) / measured conv time; peak = "
                                  f"dense bf16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s / 6 MFMAs per fp32 product",
-                "bx3_launches": n_bx3, "executed_bf16_mfma_tflops": 6.0 * flops_bx3 / (conv_ms * 1e-3) / 1e12,
+                "bx3_launches": n_bx3, "winograd_launches": n_wino,
+                "executed_bf16_mfma_tflops": 6.0 * flops_bx3 / (conv_ms * 1e-3) / 1e12,
+                "executed_bf16_mfma_frac": 6.0 * flops_bx3 / (conv_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                 "peak_bf16_mfma_tflops": PEAK_BF16_MFMA_TFLOPS, "fp32_mfma_peak_tflops": PEAK_FP32_MFMA_TFLOPS,
             }, **common)
         else:

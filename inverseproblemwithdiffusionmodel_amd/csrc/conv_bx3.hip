@@ -4,11 +4,13 @@
 // 3x3 / 1x1 contractions are computed here as
 //     x = xh + xm + xl,   xh = bf16(x), xm = bf16(x - xh), xl = bf16(x - xh - xm)      (8 + 8 + 8 significand bits:
 //     the three pieces carry the whole fp32 significand; both subtractions are exact in fp32)
-//     w * x = wh*xh + (wh*xm + wm*xh) + (wh*xl + wm*xm + wl*xh) + O(2^-27 |w x|)
+//     w * x = wh*xh + (wh*xm + wm*xh) + (wh*xl + wm*xm + wl*xh) + (wm*xl + wl*xm + wl*xl)
 // i.e. SIX v_mfma_f32_32x32x16_bf16 per 32x32x16 tile, accumulated in fp32 (every bf16 x bf16 product is exact in
-// fp32).  The three dropped products are below 2^-26 relative -- less than the rounding of one fp32 fma -- so the
-// result is fp32-faithful: tests/test_kernels_gpu.py holds it to the same float64-referenced bound as the fp32 MFMA
-// kernel.  6 x 32 cycles per 16-deep k-step against 8 x 64 for the fp32 instruction: 2.67x the matrix rate.
+// fp32).  The three dropped products are bounded by 2^-23 |w x| (|xm| <= 2^-8 |x|, |xl| <= 2^-16 |x|; typically
+// 2^-25) -- the size of ONE fp32 rounding -- so the result is fp32-faithful: against a float64 convolution its error
+// is at or below that of the exact-fp32 MFMA kernel (1.1-2.2e-6 vs 1.2-3.2e-6 of the output range on the network's
+// layer shapes), and tests/test_kernels_gpu.py holds it to a tighter float64-referenced bound than the fp32 kernel.
+// 6 x 32 cycles per 16-deep k-step against 8 x 64 for the fp32 instruction: 2.67x the matrix rate.
 //
 // GEMM view (as conv_kernel.h):  D[co, pixel] = sum_{tap, ci} W[tap][ci][co] * P[ci][pixel + tap offset]
 //   A operand (32 x 16): rows = output channels, k = 16 input channels; lane (r, h) holds k = 8h .. 8h+7 of row r.

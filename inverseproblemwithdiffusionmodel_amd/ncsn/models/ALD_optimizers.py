@@ -88,13 +88,29 @@ class ALDOptimizer(abc.ABC):
         steps, noise_scales = step_schedule(sigmas, step_lr)
         B = x_mod.shape[0]
         it = 0
+        # The score evaluation is launch-bound at small shapes (a 32x32 forward is ~300 launches): when the subclass
+        # hooks do not replace x_mod, the forward is captured once as a hipGraph on the in-place updated state.
+        plain = (type(self).init_estimation is ALDOptimizer.init_estimation
+                 and type(self).adjust_grad is ALDOptimizer.adjust_grad)
+        graph = None
+        labels = torch.zeros((B,), dtype=torch.long, device=x_mod.device)
+        if kwargs.get("use_graph", plain) and plain and x_mod.is_cuda:
+            scorenet(x_mod, labels)                              # warm-up: weight packing, allocator
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                grad_static = scorenet(x_mod, labels)
         for c in range(len(sigmas)):
             if verbose and c % max(len(sigmas) // 10, 1) == 0:
                 print(f"{c + 1}/{len(sigmas)}")
-            labels = torch.full((B,), c, dtype=torch.long, device=x_mod.device)
+            labels.fill_(c)
             x_mod = self.init_estimation(x_mod, alpha=steps[c], **kwargs)
             for s in range(n_steps_each):
-                grad = scorenet(x_mod, labels)
+                if graph is not None:
+                    graph.replay()
+                    grad = grad_static
+                else:
+                    grad = scorenet(x_mod, labels)
                 grad = self.adjust_grad(grad, x_mod, sigma=sigmas[c], **kwargs)
                 noise = None if noise_fn is None else noise_fn(x_mod).to(x_mod.device)
                 ops.langevin_step(x_mod, grad, float(steps[c]), float(noise_scales[c]), noise=noise, seed=seed,
@@ -103,9 +119,12 @@ class ALDOptimizer(abc.ABC):
                 if not final_only:
                     images.append(x_mod.to('cpu'))
         if denoise:
-            last = torch.full((B,), len(sigmas) - 1, dtype=torch.long, device=x_mod.device)
+            labels.fill_(len(sigmas) - 1)
             s2 = float(sigmas.detach().cpu()[-1] ** 2)
-            ops.langevin_step(x_mod, scorenet(x_mod, last), s2, 0.0, noise=torch.zeros_like(x_mod))
+            if graph is not None:
+                graph.replay()
+            ops.langevin_step(x_mod, grad_static if graph is not None else scorenet(x_mod, labels), s2, 0.0,
+                              noise=torch.zeros_like(x_mod))
             images.append(x_mod.to('cpu'))
         if final_only:
             return [x_mod.to('cpu')]

@@ -24,7 +24,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     with open(f) as fh:
         for row in csv.DictReader(fh):
             name = row.get("Kernel_Name") or row.get("Kernel Name")
-            if "conv_mfma_kernel" not in name or row.get("Counter_Name") != c:
+            if not any(k in name for k in ("conv_mfma_kernel", "conv_wino_kernel", "conv_bx3_kernel", "conv_wino_bx3_kernel")) \
+                    or row.get("Counter_Name") != c:
                 continue
             res[name][c].append(float(row["Counter_Value"]))
 rows, tot_f, tot_w, tot_n = [], 0.0, 0.0, 0
@@ -43,7 +44,7 @@ with open(f"profiles/{tag}_conv_pmc.csv", "w") as fh:
 per_launch = (2 * tot_f + tot_w) * 1024 / max(tot_n, 1)
 json.dump({"hbm_bytes_per_launch": per_launch, "launches_profiled": tot_n,
            "fetch_KiB_raw_total": tot_f, "write_KiB_raw_total": tot_w,
-           "note": "mean over all conv_mfma_kernel launches of bench.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+           "note": "mean over all convolution-kernel launches (conv_bx3_kernel, conv_wino_bx3_kernel; conv_mfma_kernel / conv_wino_kernel with IPDM_CONV_IMPL=f32) of bench.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                    "(gfx950 FETCH_SIZE halving corrected per MI355X_MICROARCH.md)"},
           open("profiles/conv_hbm_traffic.json", "w"), indent=1)
 print(open("profiles/conv_hbm_traffic.json").read())

@@ -152,9 +152,11 @@ def test_ald_unconditional_golden(pkg, tiny_net, golden):
     sampler = pkg.ald.ALDUnconditionalSampler((2, 1, 32, 32), tiny_net, sigmas, params, tiny_config(),
                                               device=torch.device("cuda"))
     sampler.init_x_mod = lambda: torch.from_numpy(g["uncond_x0"]).cuda()
-    x = sampler(noise_fn=_Tape(g["uncond_noise"]))[0].numpy()
+    x = sampler(noise_fn=_Tape(g["uncond_noise"]))[0].numpy()              # score forward replayed as a hipGraph
     np.testing.assert_allclose(x, g["uncond_x"], atol=1e-3)
     assert metrics.nrmse(x, g["uncond_x"]) < 1e-3
+    x_eager = sampler(noise_fn=_Tape(g["uncond_noise"]), use_graph=False)[0].numpy()
+    assert np.array_equal(x, x_eager)                                      # same launches, same bits
 
 
 def test_philox_run_is_shard_invariant(pkg, tiny_net, golden):
