@@ -351,6 +351,9 @@ int conv_bx3_dispatch(const ConvArgs& a, int ks, hipStream_t s) {
   const int f = bx3_forced_cfg();
   if (a.W <= 16) {
     if (a.dil > 1 && ks == 3) return launch_bx3_cfg<1, 2, 2, 2, 16, 4>(a, ks, s);    // 64 co x (8 x 16) px
+    if (f == 11) return launch_bx3_cfg<1, 1, 1, 4, 16, 1>(a, ks, s);                 // 32 co x (8 x 16) px
+    if (f == 12) return launch_bx3_cfg<1, 2, 1, 4, 16, 1>(a, ks, s);                 // 32 co x (16 x 16) px
+    if (f == 13) return launch_bx3_cfg<2, 2, 2, 2, 16, 1>(a, ks, s);                 // 128 co x (8 x 16) px
     return launch_bx3_cfg<1, 2, 2, 2, 16, 1>(a, ks, s);
   }
   if (a.dil > 1 && ks == 3) return launch_bx3_cfg<1, 4, 2, 2, 32, 4>(a, ks, s);

@@ -414,6 +414,287 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
   }
 }
 
+
+// ---- wide images, persistent form -----------------------------------------------------------------------------------
+// One workgroup per CU walks a list of (pixel tile, channel tile) pairs and never drains its staging pipeline: while
+// the last chunk of tile i is multiplied, chunk 0 of tile i+1 is transformed into the other V stage and its chunk 1
+// is brought into the raw stage, so only the FIRST tile of a workgroup pays the prologue (two dependent DMA round
+// trips, ~13 % of a 128-channel tile).  The epilogue therefore has to live in ONE 64 KiB stage: four rounds of
+// (channel tile, tile group) through M[pos 16][co 32][tile 32].
+// Tiles are dealt XCD-aware: XCD x owns a contiguous range of the linear tile order (channel tile fastest, so the
+// channel tiles of a pixel tile meet in that XCD's L2) and its workgroups stride through it.
+__global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int total_tiles) {
+  extern __shared__ __align__(16) float lds[];
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  if (a.dbg) t0 = __builtin_amdgcn_s_memtime();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, j = lane & 31;
+  const int HW = a.H * a.W;
+  const int n_cc = a.Cin / X_KC, n_ct = a.Cout / 32;
+  const int n_chunks = n_cc;                                  // >= 2 (launcher)
+  const int p0 = 2 * wave;
+
+  // ---- this workgroup's tile list: first, stride, end (linear tile order, channel tile fastest) ----
+  const int S = gridDim.x / 8;                                // workgroups per XCD (grid is a multiple of 8)
+  const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+  const int q = total_tiles / 8, r8 = total_tiles % 8;
+  const int x_start = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+  const int x_end = x_start + q + (xcd < r8 ? 1 : 0);
+  int tile = x_start + slot;
+  if (tile >= x_end) return;                                  // uniform: whole workgroup
+
+  struct Geo { int b, y0, x0, co_tile; };
+  auto geo_of = [&](int L) {
+    Geo g;
+    g.co_tile = L % a.co_tiles;
+    int t = L / a.co_tiles;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    g.y0 = (t % a.tiles_y) * (2 * X_TY);
+    g.x0 = tx * (2 * X_TX);
+    g.b = t / a.tiles_y;
+    return g;
+  };
+
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((size_t)a.B * a.Cin * HW * 4), 0x00020000);
+  float* const rs = lds + 2 * X_V_ELEMS;
+  const int mytile = tid & 63;
+
+  // raw stage by LDS-DMA: wave w brings in channels 2w, 2w+1 (6 x 64 floats each)
+  int dma_off[6];
+  int dma_b = 0;                                              // image index the offsets belong to
+  auto set_dma_geo = [&](const Geo& g) {
+    dma_b = g.b;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int e = k * 64 + lane;
+      const int rr = e / X_RC, c = e - rr * X_RC;
+      const int gy = g.y0 - 1 + rr, gx = g.x0 - 1 + c;
+      const bool ok = e < X_RR * X_RC && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      dma_off[k] = ok ? (gy * a.W + gx) * 4 : 0x40000000;
+    }
+  };
+  auto issue_dma = [&](int chunk) {
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl) {
+      const int kc = 2 * wave + cl;
+      const int soff = (int)(((size_t)dma_b * a.Cin + chunk * X_KC + kc) * HW * 4);
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(rs + kc * X_RCH + k * 64), 4,
+                                                 dma_off[k], soff, 0, 0);
+    }
+  };
+  float dreg[16];
+  const int r_lane = (2 * (mytile / X_TX)) * X_RC + 2 * (mytile % X_TX);
+  auto read_patch = [&](int kc) {
+    const float* rp = rs + kc * X_RCH + r_lane;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const float2 lo = *reinterpret_cast<const float2*>(rp + rr * X_RC);
+      const float2 hi = *reinterpret_cast<const float2*>(rp + rr * X_RC + 2);
+      dreg[rr * 4 + 0] = lo.x; dreg[rr * 4 + 1] = lo.y; dreg[rr * 4 + 2] = hi.x; dreg[rr * 4 + 3] = hi.y;
+    }
+  };
+  auto store_patch = [&](float* st, int kc) {
+    const float(&dd)[16] = dreg;
+    float tmp[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      tmp[0 * 4 + c] = dd[0 * 4 + c] - dd[2 * 4 + c];
+      tmp[1 * 4 + c] = dd[1 * 4 + c] + dd[2 * 4 + c];
+      tmp[2 * 4 + c] = dd[2 * 4 + c] - dd[1 * 4 + c];
+      tmp[3 * 4 + c] = dd[1 * 4 + c] - dd[3 * 4 + c];
+    }
+    float* vs = st + kc * X_TILES + mytile;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      vs[(rr * 4 + 0) * X_KC * X_TILES] = tmp[rr * 4 + 0] - tmp[rr * 4 + 2];
+      vs[(rr * 4 + 1) * X_KC * X_TILES] = tmp[rr * 4 + 1] + tmp[rr * 4 + 2];
+      vs[(rr * 4 + 2) * X_KC * X_TILES] = tmp[rr * 4 + 2] - tmp[rr * 4 + 1];
+      vs[(rr * 4 + 3) * X_KC * X_TILES] = tmp[rr * 4 + 1] - tmp[rr * 4 + 3];
+    }
+  };
+
+  const uint4* wq = reinterpret_cast<const uint4*>(a.wt);
+  const size_t pos_stride = (size_t)n_cc * n_ct * 192;
+  auto load_A = [&](bf16x8 (&fr)[2][3], int p, int cc, int co_tile) {
+    const uint4* base = wq + (size_t)p * pos_stride + ((size_t)cc * n_ct + co_tile * 2) * 192 + lane;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) fr[c][s] = __builtin_bit_cast(bf16x8, base[c * 192 + s * 64]);
+  };
+  const int b_lane = (8 * h) * X_TILES + j;
+  auto load_B = [&](float (&raw)[8], const float* cur, int pi, int tg) {
+    const float* bp = cur + (p0 + pi) * (X_KC * X_TILES) + tg * 32 + b_lane;
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) raw[qq] = bp[qq * X_TILES];
+  };
+
+  f32x16 acc[2][2][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) acc[i >> 2][(i >> 1) & 1][i & 1][rr] = 0.f;
+  };
+  zero_acc();
+
+  // ---- prologue of the first tile ----
+  Geo cur_g = geo_of(tile);
+  bf16x8 afr[2][2][3];
+  load_A(afr[0], p0, 0, cur_g.co_tile);
+  set_dma_geo(cur_g);
+  issue_dma(0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  read_patch(2 * wave);
+  store_patch(lds, 2 * wave);
+  read_patch(2 * wave + 1);
+  store_patch(lds, 2 * wave + 1);
+  __syncthreads();
+  issue_dma(1);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (a.dbg) t1 = __builtin_amdgcn_s_memtime();
+
+  int g = 0;                                                  // chunks done so far: stage parity
+  while (true) {
+    const int next_tile = tile + S;
+    const bool has_next = next_tile < x_end;
+    const Geo next_g = geo_of(has_next ? next_tile : tile);
+    for (int ch = 0; ch < n_chunks; ++ch, ++g) {
+      const float* cur = lds + (g & 1) * X_V_ELEMS;
+      float* nxt = lds + ((g + 1) & 1) * X_V_ELEMS;
+      // the chunk two ahead in the stream (DMA target) and the one after this (A fragments of position p0)
+      const bool dma_next = ch + 2 >= n_chunks;
+      const int dma_chunk = dma_next ? ch + 2 - n_chunks : ch + 2;
+      if (ch + 2 == n_chunks) set_dma_geo(next_g);            // from here on the raw stage belongs to the next tile
+      const bool a_next = ch + 1 >= n_chunks;
+      const int a_chunk = a_next ? 0 : ch + 1;
+      const int a_cot = a_next ? next_g.co_tile : cur_g.co_tile;
+      bf16x8 bs[2][3];
+      float raw[8];
+      load_B(raw, cur, 0, 0);
+      split3(raw, bs[0][0], bs[0][1], bs[0][2]);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<4>([&](auto sc) {
+        constexpr int st = decltype(sc)::value;
+        constexpr int pi = st >> 1, tg = st & 1;
+        if constexpr (st < 3) load_B(raw, cur, (st + 1) >> 1, (st + 1) & 1);
+        if constexpr (st == 0) {
+          read_patch(2 * wave);
+          store_patch(nxt, 2 * wave);
+          read_patch(2 * wave + 1);
+          store_patch(nxt, 2 * wave + 1);
+          load_A(afr[1], p0 + 1, ch, cur_g.co_tile);
+        }
+        if constexpr (st == 1) issue_dma(dma_chunk);
+        if constexpr (st == 2) load_A(afr[0], p0, a_chunk, a_cot);
+        if constexpr (st < 3) split3(raw, bs[(st + 1) & 1][0], bs[(st + 1) & 1][1], bs[(st + 1) & 1][2]);
+        const bf16x8 bh = bs[st & 1][0], bm = bs[st & 1][1], bl = bs[st & 1][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          f32x16 v = acc[pi][c][tg];
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][2], bh, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bl, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][1], bm, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][1], bh, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bm, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bh, v, 0, 0, 0);
+          acc[pi][c][tg] = v;
+        }
+        if constexpr (st < 3) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        constexpr bool XFORM = st == 0;
+        if constexpr (XFORM) __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, XFORM ? 12 : 5, 0);
+          if constexpr (XFORM) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+          if constexpr (st < 3) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (st == 0) __syncthreads();               // everyone has read the raw stage
+      });
+      __builtin_amdgcn_s_waitcnt(0);                          // the DMA has landed
+      __syncthreads();
+    }
+    if (a.dbg) t2 = __builtin_amdgcn_s_memtime();
+
+    // ---- epilogue of this tile in the stage its last chunk was read from (the other stage and the raw stage already
+    //      hold the next tile); rounds over (channel tile c, tile group tg) ----
+    float* ms = lds + ((g - 1) & 1) * X_V_ELEMS;              // M[pos 16][co 32][tile 32]
+    const int etile = tid & 31, ecg = tid >> 5;               // this thread: tile, channels 2*ecg, 2*ecg+1 of the 32
+    const int co0 = cur_g.co_tile * X_CO;
+    static_for<4>([&](auto rc) {
+      constexpr int rnd = decltype(rc)::value;
+      constexpr int c = rnd >> 1, tg = rnd & 1;
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int col = (rr & 3) + 8 * (rr >> 2) + 4 * h;
+          ms[((p0 + pi) * 32 + col) * 32 + j] = acc[pi][c][tg][rr];
+        }
+      __syncthreads();
+      const int T = tg * 32 + etile;
+      const int oy = cur_g.y0 + 2 * (T / X_TX), ox = cur_g.x0 + 2 * (T % X_TX);
+      if (oy < a.H && ox < a.W) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int cl = ecg * 2 + i;
+          const int co = co0 + c * 32 + cl;
+          float m[16];
+#pragma unroll
+          for (int p = 0; p < 16; ++p) m[p] = ms[(p * 32 + cl) * 32 + etile];
+          float tt[2][4];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            tt[0][qq] = m[0 * 4 + qq] + m[1 * 4 + qq] + m[2 * 4 + qq];
+            tt[1][qq] = m[1 * 4 + qq] - m[2 * 4 + qq] - m[3 * 4 + qq];
+          }
+          const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            float y0v = tt[ii][0] + tt[ii][1] + tt[ii][2] + bias;
+            float y1v = tt[ii][1] - tt[ii][2] - tt[ii][3] + bias;
+            const size_t o = ((size_t)cur_g.b * a.Cout + co) * HW + (size_t)(oy + ii) * a.W + ox;
+            if (a.residual) {
+              const float2 rr2 = *reinterpret_cast<const float2*>(a.residual + o);
+              y0v += rr2.x;
+              y1v += rr2.y;
+            }
+            if (a.out) *reinterpret_cast<float2*>(a.out + o) = make_float2(y0v, y1v);
+            if (a.out_act) {
+              const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
+              const float e1 = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
+              *reinterpret_cast<float2*>(a.out_act + o) = make_float2(e0, e1);
+            }
+          }
+        }
+      }
+      __syncthreads();                                        // M is rewritten by the next round / the next tile's V
+    });
+    if (!has_next) break;
+    zero_acc();
+    tile = next_tile;
+    cur_g = next_g;
+  }
+  if (a.dbg) {
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      unsigned long long* d4 = a.dbg + (size_t)blockIdx.x * 4;
+      d4[0] = t0; d4[1] = t1; d4[2] = t2; d4[3] = t3;
+    }
+  }
+}
+
 bool x_small(const ConvArgs& a) { return a.W < 32 || a.dil > 1; }
 
 }  // namespace
@@ -445,11 +726,35 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  if (small) hipLaunchKernelGGL(conv_wino_bx3_kernel<true>, dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
-  else hipLaunchKernelGGL(conv_wino_bx3_kernel<false>, dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
+  static int persist = -1;                       // IPDM_WBX3_PERSIST=0: one workgroup per tile (tuning / fallback)
+  if (persist < 0) {
+    const char* e = getenv("IPDM_WBX3_PERSIST");
+    persist = e ? atoi(e) : 1;
+  }
+  if (small) {
+    hipLaunchKernelGGL(conv_wino_bx3_kernel<true>, dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
+  } else if (persist && a.Cin >= 2 * X_KC) {
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) == hipSuccess &&
+          hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8)
+        n_cu = v;
+      else
+        n_cu = 256;                                            // MI355X
+    }
+    const int per_xcd = (int)((nblk + 7) / 8);
+    const int S = per_xcd < n_cu / 8 ? per_xcd : n_cu / 8;       // one 128+24 KiB workgroup per CU
+    hipLaunchKernelGGL(conv_wino_bx3_wide_kernel, dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+  } else {
+    hipLaunchKernelGGL(conv_wino_bx3_kernel<false>, dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
+  }
   return ipdm_launch_status();
 }
 

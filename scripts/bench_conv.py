@@ -18,7 +18,7 @@ FUSED = os.environ.get("BENCH_FUSED") == "1"   # ELU + InstanceNorm++ coefficien
 SHAPES = [  # (count per forward, Cin, Cout, H, dil)
     (18, 128, 128, 128, 1), (9, 128, 128, 64, 1), (8, 256, 256, 64, 1), (17, 256, 256, 32, 1),
     (25, 256, 256, 16, 1), (16, 512, 512, 16, 2), (5, 512, 512, 16, 4), (1, 128, 256, 128, 1),
-    (1, 256, 512, 16, 2), (1, 1, 128, 128, 1), (1, 128, 1, 128, 1),
+    (1, 256, 512, 16, 2), (1, 1, 128, 128, 1), (1, 128, 1, 128, 1), (16, 512, 512, 16, 1),
 ]
 
 
