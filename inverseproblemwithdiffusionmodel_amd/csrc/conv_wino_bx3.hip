@@ -702,7 +702,8 @@ bool x_small(const ConvArgs& a) { return a.W < 32 || a.dil > 1; }
 bool wino_bx3_ok(const ConvArgs& a, int ks) {
   if (!(ks == 3 && a.D == 1 && a.Cin % X_KC == 0 && a.Cout % X_CO == 0 && !a.coef && a.act == IPDM_ACT_NONE)) return false;
   if (a.dil < 1 || a.dil > 4) return false;
-  if ((size_t)a.B * a.Cin * a.H * a.W * 4 >= 0x1fffffffull) return false;   // buffer offsets + padding marker < 2^30
+  // buffer descriptors: the tensor must end below the padding marker (2^29 + 2^29 register path, 2^30 DMA path)
+  if ((size_t)a.B * a.Cin * a.H * a.W * 4 >= (x_small(a) ? 0x1fffffffull : 0x3fffffffull)) return false;
   if (x_small(a)) return a.H % (2 * a.dil) == 0 && a.W % (2 * a.dil) == 0 && (a.H * a.W) / 4 >= 32;
   return a.H % 2 == 0 && a.W % 2 == 0 && a.H >= 8;
 }

@@ -53,9 +53,18 @@ class Conv(nn.Module):
             self._packed = (v, ops.conv_weight(self.weight.data))
         return self._packed[1]
 
+    def packed_wino(self):
+        v = (self.weight._version, self.weight.data_ptr())
+        if getattr(self, "_wino", None) is None or self._wino[0] != v:
+            self._wino = (v, ops.conv_wino_bx3_weight(self.weight.data))
+        return self._wino[1]
+
     def forward(self, x, residual=None):
-        return ops.conv2d(x, self.packed(), None if self.bias is None else self.bias.data, residual=residual,
-                          dilation=self.dilation)
+        bias = None if self.bias is None else self.bias.data
+        if (ops.CONV_IMPL == "bx3" and self.kernel_size == 3
+                and ops.wino_bx3_pays(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation, x.shape[0])):
+            return ops.conv2d_wino_bx3(x, self.packed_wino(), bias, residual, dilation=self.dilation)
+        return ops.conv2d(x, self.packed(), bias, residual=residual, dilation=self.dilation)
 
 
 def ddpm_conv1x1(in_planes, out_planes, stride=1, bias=True, init_scale=1., padding=0):

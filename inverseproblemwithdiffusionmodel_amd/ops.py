@@ -539,10 +539,12 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
     return (out, out_act) if want_act else out
 
 
-def wino_bx3_pays(Cin, Cout, H, W, dilation=1):
+def wino_bx3_pays(Cin, Cout, H, W, dilation=1, B=1):
     """dispatch rule measured on MI355X (scripts/bench_conv.py): the split-bf16 Winograd kernel beats the direct
     split-bf16 kernel wherever it is eligible, except on undilated images of 16 pixels or less across (a single
     64-tile workgroup per image and channel tile leaves most of the chip idle)"""
     if W <= 16 and dilation == 1:
+        return False
+    if B * Cin * H * W * 4 >= (0x1fffffff if (W < 32 or dilation > 1) else 0x3fffffff):   # buffer-descriptor reach
         return False
     return conv_wino_bx3_supported(Cin, Cout, H, W, dilation)
