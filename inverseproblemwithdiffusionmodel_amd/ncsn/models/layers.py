@@ -94,7 +94,7 @@ class Conv2d(nn.Module):
         bias = None if self.bias is None else self.bias.data
         if (USE_WINOGRAD and ops.CONV_IMPL == "f32" and self.ndim == 2 and self.kernel_size == 3 and coef is None and act == ops.ACT_NONE
                 and out is None
-                and ops.conv_wino_supported(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation, x.shape[0])):
+                and ops.conv_wino_supported(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation)):
             return ops.conv2d_wino(x, self.packed_wino(), bias, residual, act_out=act_out, raw=raw,
                                    dilation=self.dilation)
         if (USE_WINOGRAD and ops.CONV_IMPL == "bx3" and self.ndim == 2 and self.kernel_size == 3 and coef is None

@@ -103,6 +103,30 @@ def test_full_size_ncsnv2_deepest(pkg, golden):
     ref = g["y"]
     assert np.abs(y - ref).max() <= 2e-4 * np.abs(ref).max()
     assert metrics.nrmse(y, ref) < 1e-4
+    # size-independent properties at the production size:
+    # (1) per-image normalisation => a sample's score does not depend on what else is in the batch, bit for bit
+    #     (persistent tile walk, Winograd / direct dispatch and LDS-DMA staging are all batch-independent)
+    from inverseproblemwithdiffusionmodel_amd import ops
+    xg, lg = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["labels"]).cuda()
+    x3 = torch.cat([xg, xg[:1] * 0.5 + 3.0], dim=0)
+    l3 = torch.cat([lg, lg[:1]], dim=0)
+    y3 = net(x3, l3)
+    assert torch.equal(y3[:xg.shape[0]].cpu(), torch.from_numpy(y))
+    # (2) the two independently written kernel families (split-bf16 vs exact-fp32 MFMA, each with its own Winograd)
+    #     agree far inside the parity tolerance
+    impl = ops.CONV_IMPL
+    try:
+        ops.CONV_IMPL = "f32" if impl == "bx3" else "bx3"
+        for m in net.modules():
+            if hasattr(m, "_packed"):
+                m._packed, m._wino = None, None
+                if hasattr(m, "_packed_version"):
+                    m._packed_version = None
+        y_other = net(xg, lg).cpu().numpy()
+    finally:
+        ops.CONV_IMPL = impl
+    assert metrics.nrmse(y_other, y) < 2e-5
+    assert np.abs(y_other - ref).max() <= 2e-4 * np.abs(ref).max()
 
 
 class _Tape:
