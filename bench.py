@@ -261,6 +261,33 @@ def main():
                 "winograd_launches": n_wino, "executed_mfma_tflops": executed / (conv_ms * 1e-3) / 1e12,
                 "executed_mfma_frac": executed / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             }, **common)
+        if world == 1 and not args.full and ops.CONV_IMPL == "bx3":
+            # the same iteration through the exact-fp32-MFMA kernel family (conv_mfma_kernel + fp32 Winograd),
+            # reported beside the headline so that the split-bf16 result can be judged against it
+            try:
+                ops.CONV_IMPL = "f32"
+                for m in prob.scorenet.modules():
+                    if hasattr(m, "_packed"):
+                        m._packed, m._wino = None, None
+                        if hasattr(m, "_packed_version"):
+                            m._packed_version = None
+                alt = engine.IterationRunner(prob, seed=0, sample_offset=offset, use_graph=not args.no_graph)
+                for k in order[:3]:
+                    alt.run(int(k))
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n_alt = min(steps, 20)
+                for k in order[warm:warm + n_alt]:
+                    alt.run(int(k))
+                torch.cuda.synchronize()
+                alt_ms = (time.perf_counter() - t1) * 1e3 / n_alt
+                out["alt_fp32_mfma"] = {
+                    "ms_per_step": alt_ms, "value": total / (alt_ms * 1e-3 * ITER_PER_RECON), "steps": n_alt,
+                    "note": "IPDM_CONV_IMPL=f32: v_mfma_f32_32x32x2_f32 direct + fp32 Winograd kernels, same graph "
+                            "structure; not the headline",
+                }
+            finally:
+                ops.CONV_IMPL = "bx3"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters)
         print(json.dumps(out), flush=True)
