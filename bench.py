@@ -219,7 +219,10 @@ def main():
         # Winograd F(2x2,3x3) launches execute 16 instead of 36 multiply-adds per 2x2 output tile
         executed = sum(r["flops"] / (2.25 if r.get("wino") else 1.0) for r in reps[0])
         n_wino = sum(1 for r in reps[0] if r.get("wino"))
-        bytes_alg = sum(4.0 * r["B"] * r["H"] * r["W"] * (r["Cin"] + r["Cout"]) for r in reps[0]) / len(reps[0])
+        # algorithmic HBM bytes of a launch: input + (residual) read once, each requested output written once,
+        # weights read once
+        bytes_alg = sum(4.0 * r["B"] * r["H"] * r["W"] * (r["Cin"] + r["Cout"] * (int(r.get("res", False)) + r.get("n_out", 1)))
+                        + 4.0 * r["Cin"] * r["Cout"] * r["k"] ** 2 for r in reps[0]) / len(reps[0])
         conv_ms = float(np.median([sum(r["ms"] for r in rep) for rep in reps]))
         log(f"conv census: {len(reps[0])} launches, {conv_ms:.2f} ms, {flops / 1e12:.3f} TFLOP per step")
         achieved = flops / (conv_ms * 1e-3) / 1e12

@@ -345,7 +345,8 @@ def conv2d_wino(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dila
          B, Cin, Cout, H, W, dilation, _stream())
     if CONV_TRACE is not None:
         e1.record()
-        CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, e0=e0, e1=e1))
+        CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, res=residual is not None,
+                               n_out=int(raw) + int(want_act), e0=e0, e1=e1))
     return (out, out_act) if want_act else out
 
 
@@ -369,7 +370,8 @@ def conv3d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1,
          act_out, B, Cin, Cout, D, H, W, k, dilation, _stream())
     if CONV_TRACE is not None:
         e1.record()
-        CONV_TRACE.append(dict(B=B * D, Cin=Cin, Cout=Cout, H=H, W=W, k=k, dil=dilation, taps3d=kk, e0=e0, e1=e1))
+        CONV_TRACE.append(dict(B=B * D, Cin=Cin, Cout=Cout, H=H, W=W, k=k, dil=dilation, taps3d=kk, res=residual is not None,
+                               n_out=int(raw) + int(want_act), e0=e0, e1=e1))
     return (out, out_act) if want_act else out
 
 
@@ -423,7 +425,8 @@ def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1,
          act_out, B, Cin, Cout, H, W, k, dilation, int(bool(pool2)), _stream())
     if CONV_TRACE is not None:
         e1.record()
-        CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, dil=dilation, e0=e0, e1=e1))
+        CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, dil=dilation, res=residual is not None,
+                               n_out=int(raw) + int(want_act), e0=e0, e1=e1))
     return (out, out_act) if want_act else out
 
 
@@ -500,7 +503,8 @@ def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=
              _ptr(out_act), act_out, B, Cin, wq.Cout, H, W, k, dilation, _stream())
     if CONV_TRACE is not None:
         e1.record()
-        CONV_TRACE.append(dict(B=B * D, Cin=Cin, Cout=wq.Cout, H=H, W=W, k=k, dil=dilation, bx3=True,
+        CONV_TRACE.append(dict(B=B * D, Cin=Cin, Cout=wq.Cout, H=H, W=W, k=k, dil=dilation, bx3=True, res=residual is not None,
+                               n_out=int(raw) + int(want_act),
                                taps3d=wq.kk if vol else None, e0=e0, e1=e1))
     return (out, out_act) if want_act else out
 
@@ -535,7 +539,8 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
          B, Cin, Cout, H, W, dilation, _stream())
     if CONV_TRACE is not None:
         e1.record()
-        CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, e0=e0, e1=e1))
+        CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, res=residual is not None,
+                               n_out=int(raw) + int(want_act), e0=e0, e1=e1))
     return (out, out_act) if want_act else out
 
 

@@ -4,7 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from inverseproblemwithdiffusionmodel_amd import ops, _lib
 B = 28
-for ci, co, hw, dil in [(128, 128, 128, 1), (256, 256, 64, 1), (256, 256, 16, 1)]:
+for ci, co, hw, dil in [(128, 128, 128, 1), (256, 256, 16, 1), (512, 512, 16, 1)]:
     x = torch.randn(B, ci, hw, hw, device="cuda"); w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
     wq = ops.conv_bx3_weight(w)
     buf = torch.zeros(1 << 20, dtype=torch.int64, device="cuda")
@@ -24,4 +24,4 @@ for ci, co, hw, dil in [(128, 128, 128, 1), (256, 256, 64, 1), (256, 256, 16, 1)
     print(f"{ci}->{co}@{hw}: blocks {nblk}; shader cycles: prologue {pro.median():.0f} loop {loop.median():.0f} "
           f"({loop.median() / nch:.1f}/chunk) epilogue {epi.median():.0f} total {(t[:,3]-t[:,0]).median():.0f}; "
           f"kernel span {span:.0f} cycles in {ms * 1e3:.0f} us -> {span / ms / 1e6:.2f} GHz; blocks/CU {nblk / 256:.1f}; "
-          f"MFMA-bound loop = {nch * 9 * 4 * 6 * 32} cycles per wave (x2 waves per SIMD)")
+          f"MFMA-bound loop = {nch * 9 * (4 if hw > 16 else 2) * 6 * 32} cycles per wave")
