@@ -10,15 +10,29 @@
 namespace {
 
 // ---- InstanceNorm++ ---------------------------------------------------------------------------
-// pass 1: one workgroup per (b, c) plane: mean and 1/sqrt(biased var + 1e-5), two sweeps (2nd is L2-hot)
+// pass 1: one workgroup per (b, c) plane: mean and 1/sqrt(biased var + 1e-5), two sweeps.  Planes of up to 128x128
+// are held in registers between the sweeps (16 float4 per thread): with thousands of 64 KiB planes in flight the
+// second sweep would otherwise miss L2 and read HBM again.  Same arithmetic and summation order on both paths.
+template <bool REG>
 __global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restrict__ x, float* __restrict__ coef,
                                                           int HW) {
   __shared__ double red[4];
   const float* p = x + (size_t)blockIdx.x * HW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+  const bool vec = REG || ((HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0));
+  float4 keep[16];
   float s = 0.f;
-  if (vec) {
+  if constexpr (REG) {
+    const int n4 = HW / 4;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = tid + k * 256;
+      keep[k] = i < n4 ? reinterpret_cast<const float4*>(p)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (tid + k * 256 < n4) s += (keep[k].x + keep[k].y) + (keep[k].z + keep[k].w);
+  } else if (vec) {
     for (int i = tid; i < HW / 4; i += 256) {
       float4 v = reinterpret_cast<const float4*>(p)[i];
       s += (v.x + v.y) + (v.z + v.w);
@@ -32,7 +46,16 @@ __global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restric
   const float mean = (float)((red[0] + red[1] + red[2] + red[3]) / (double)HW);
   __syncthreads();
   float q = 0.f;
-  if (vec) {
+  if constexpr (REG) {
+    const int n4 = HW / 4;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (tid + k * 256 < n4) {
+        const float a = keep[k].x - mean, b = keep[k].y - mean, c = keep[k].z - mean, d = keep[k].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+      }
+    }
+  } else if (vec) {
     for (int i = tid; i < HW / 4; i += 256) {
       float4 v = reinterpret_cast<const float4*>(p)[i];
       float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
@@ -183,6 +206,60 @@ __global__ __launch_bounds__(256) void maxpool5_kernel(const float* __restrict__
   }
 }
 
+// float4 path (W % 4 == 0): a thread owns 4 adjacent columns x MP_R rows and slides a five-row window of row maxima
+// down its strip in registers -- no LDS, no barriers; the three float4 loads per row overlap with the neighbouring
+// threads' and are served by L1.  max is exact, so the result is bit-identical to the tiled kernel.
+constexpr int MP_R = 8;
+__global__ __launch_bounds__(256) void maxpool5_strip_kernel(const float* __restrict__ x, float* __restrict__ y, int H,
+                                                             int W, int64_t n_items) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_items) return;
+  const int WG = W / 4, HS = (H + MP_R - 1) / MP_R;
+  const int xg = (int)(idx % WG);
+  const int64_t t = idx / WG;
+  const int strip = (int)(t % HS);
+  const int64_t plane = t / HS;
+  const int x0 = xg * 4, y0 = strip * MP_R;
+  const float* p = x + plane * (int64_t)H * W;
+  float* o = y + plane * (int64_t)H * W;
+  const float NI = -INFINITY;
+  float rm[5][4];
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rm[k][j] = NI;
+#pragma unroll
+  for (int i = 0; i < MP_R + 4; ++i) {
+    const int r = y0 - 2 + i;
+    float4 a = make_float4(NI, NI, NI, NI), b = a, c = a;
+    if (r >= 0 && r < H) {
+      const float* row = p + (int64_t)r * W + x0;
+      b = *reinterpret_cast<const float4*>(row);
+      if (x0 >= 4) a = *reinterpret_cast<const float4*>(row - 4);
+      if (x0 + 4 < W) c = *reinterpret_cast<const float4*>(row + 4);
+    }
+    // v0..v7 = columns x0-2 .. x0+5
+    const float v0 = a.z, v1 = a.w, v2 = b.x, v3 = b.y, v4 = b.z, v5 = b.w, v6 = c.x, v7 = c.y;
+    const float m12 = fmaxf(v1, v2), m34 = fmaxf(v3, v4), m56 = fmaxf(v5, v6);
+    float* cur = rm[i % 5];
+    cur[0] = fmaxf(fmaxf(v0, m12), m34);
+    cur[1] = fmaxf(fmaxf(m12, m34), v5);
+    cur[2] = fmaxf(fmaxf(v2, m34), m56);
+    cur[3] = fmaxf(fmaxf(m34, m56), v7);
+    if (i >= 4) {                                             // rows r-4 .. r are in the ring: output row r-2
+      const int ro = r - 2;
+      if (ro < H) {
+        float4 out;
+        out.x = fmaxf(fmaxf(fmaxf(rm[0][0], rm[1][0]), fmaxf(rm[2][0], rm[3][0])), rm[4][0]);
+        out.y = fmaxf(fmaxf(fmaxf(rm[0][1], rm[1][1]), fmaxf(rm[2][1], rm[3][1])), rm[4][1]);
+        out.z = fmaxf(fmaxf(fmaxf(rm[0][2], rm[1][2]), fmaxf(rm[2][2], rm[3][2])), rm[4][2]);
+        out.w = fmaxf(fmaxf(fmaxf(rm[0][3], rm[1][3]), fmaxf(rm[2][3], rm[3][3])), rm[4][3]);
+        *reinterpret_cast<float4*>(o + (int64_t)ro * W + x0) = out;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void meanpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n_out,
                                                         int H, int W) {
   const int OH = H / 2, OW = W / 2;
@@ -217,6 +294,43 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__
   }
 }
 
+// ow % 4 == 0: four adjacent outputs per thread (one row / plane decomposition, float4 read-modify-write of `out`);
+// per-element arithmetic identical to bilinear_kernel
+__global__ __launch_bounds__(256) void bilinear4_kernel(const float* __restrict__ x, float* out, int64_t n_items, int ih,
+                                                        int iw, int oh, int ow, float sh, float sw, int accumulate, int act) {
+  const int og = ow / 4;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < n_items; it += (int64_t)gridDim.x * 256) {
+    const int xg = (int)(it % og);
+    const int64_t t = it / og;
+    const int oy = (int)(t % oh);
+    const int64_t plane = t / oh;
+    const float fy = sh * oy;
+    const int y0 = (int)fy;
+    const int yp = y0 < ih - 1 ? 1 : 0;
+    const float ly1 = fy - y0, ly0 = 1.f - ly1;
+    const float* r0 = x + (plane * ih + y0) * (int64_t)iw;
+    const float* r1 = r0 + yp * iw;
+    float* po = out + (plane * oh + oy) * (int64_t)ow + xg * 4;
+    float4 acc = accumulate ? *reinterpret_cast<const float4*>(po) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float res[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ox = xg * 4 + j;
+      const float fx = sw * ox;
+      const int x0 = (int)fx;
+      const int xp = x0 < iw - 1 ? 1 : 0;
+      const float lx1 = fx - x0, lx0 = 1.f - lx1;
+      res[j] = ly0 * (lx0 * r0[x0] + lx1 * r0[x0 + xp]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x0 + xp]);
+    }
+    float4 o;
+    o.x = ipdm_act(accumulate ? acc.x + res[0] : res[0], act);
+    o.y = ipdm_act(accumulate ? acc.y + res[1] : res[1], act);
+    o.z = ipdm_act(accumulate ? acc.z + res[2] : res[2], act);
+    o.w = ipdm_act(accumulate ? acc.w + res[3] : res[3], act);
+    *reinterpret_cast<float4*>(po) = o;
+  }
+}
+
 struct ActOp {
   int act;
   __device__ float operator()(float v) const { return ipdm_act(v, act); }
@@ -234,7 +348,11 @@ extern "C" int ipdm_instnorm_plus_coef_f32(const float* x, const float* alpha, c
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && alpha && gamma && coef);
   hipStream_t s = ipdm_stream(stream);
-  hipLaunchKernelGGL(plane_stats_kernel, dim3(B * C), dim3(256), 0, s, x, coef, HW);
+  // register-resident planes: float4-aligned (HW % 4 == 0 keeps every plane of a 16-byte aligned tensor aligned)
+  if (HW % 4 == 0 && HW <= 16384 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+    hipLaunchKernelGGL(plane_stats_kernel<true>, dim3(B * C), dim3(256), 0, s, x, coef, HW);
+  else
+    hipLaunchKernelGGL(plane_stats_kernel<false>, dim3(B * C), dim3(256), 0, s, x, coef, HW);
   hipLaunchKernelGGL(instnorm_plus_coef_kernel, dim3(B), dim3(256), 0, s, coef, alpha, gamma, beta, C);
   return ipdm_launch_status();
 }
@@ -301,6 +419,14 @@ extern "C" int ipdm_maxpool5_f32(const float* x, float* y, int planes, int H, in
   if (planes == 0) return IPDM_OK;
   IPDM_REQUIRE(x && y && x != y);
   int tiles = ((H + MP_T - 1) / MP_T) * ((W + MP_T - 1) / MP_T);
+  if (W % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+    const int64_t n_items = (int64_t)planes * (W / 4) * ((H + MP_R - 1) / MP_R);
+    if ((n_items + 255) / 256 <= 0x7fffffff) {
+      hipLaunchKernelGGL(maxpool5_strip_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, ipdm_stream(stream), x, y,
+                         H, W, (long long)n_items);
+      return ipdm_launch_status();
+    }
+  }
   for (int p0 = 0; p0 < planes; p0 += 65535) {
     int np = (planes - p0) < 65535 ? (planes - p0) : 65535;
     hipLaunchKernelGGL(maxpool5_kernel, dim3(tiles, np), dim3(256), 0, ipdm_stream(stream), x + (size_t)p0 * H * W,
@@ -327,6 +453,11 @@ extern "C" int ipdm_bilinear_f32(const float* x, float* out, int planes, int in_
   float sh = out_h > 1 ? (float)(in_h - 1) / (float)(out_h - 1) : 0.f;
   float sw = out_w > 1 ? (float)(in_w - 1) / (float)(out_w - 1) : 0.f;
   int64_t n_out = (int64_t)planes * out_h * out_w;
+  if (out_w % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    hipLaunchKernelGGL(bilinear4_kernel, dim3(ipdm_ew_grid(n_out / 4, 256)), dim3(256), 0, ipdm_stream(stream), x, out,
+                       (long long)(n_out / 4), in_h, in_w, out_h, out_w, sh, sw, accumulate, act);
+    return ipdm_launch_status();
+  }
   hipLaunchKernelGGL(bilinear_kernel, dim3(ipdm_ew_grid(n_out, 256)), dim3(256), 0, ipdm_stream(stream), x, out,
                      (long long)n_out, in_h, in_w, out_h, out_w, sh, sw, accumulate, act);
   return ipdm_launch_status();
