@@ -423,7 +423,13 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
 // (channel tile, tile group) through M[pos 16][co 32][tile 32].
 // Tiles are dealt XCD-aware: XCD x owns a contiguous range of the linear tile order (channel tile fastest, so the
 // channel tiles of a pixel tile meet in that XCD's L2) and its workgroups stride through it.
+// TX x TY tiles per workgroup: 16 x 4 (8 x 32 output pixels) for wide images, 8 x 8 (16 x 16) for 16-pixel images, whose
+// workgroups are dealt channel-tile-major (CO_MAJOR: an XCD keeps ONE channel tile's 3 MiB of Winograd weights in L2).
+template <int TX, int TY, bool CO_MAJOR>
 __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int total_tiles) {
+  static_assert(TX * TY == X_TILES, "64 tiles per workgroup");
+  constexpr int RC = 2 * TX + 2, RR = 2 * TY + 2;            // raw region: 34 x 10 or 18 x 18 pixels (<= X_RCH)
+  static_assert(RC * RR <= X_RCH, "raw region fits its LDS slot");
   extern __shared__ __align__(16) float lds[];
   unsigned long long t0 = 0, t1 = 0, t2 = 0;
   if (a.dbg) t0 = __builtin_amdgcn_s_memtime();
@@ -448,12 +454,13 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   struct Geo { int b, y0, x0, co_tile; };
   auto geo_of = [&](int L) {
     Geo g;
-    g.co_tile = L % a.co_tiles;
-    int t = L / a.co_tiles;
+    const int n_px = total_tiles / a.co_tiles;
+    g.co_tile = CO_MAJOR ? L / n_px : L % a.co_tiles;
+    int t = CO_MAJOR ? L % n_px : L / a.co_tiles;
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
-    g.y0 = (t % a.tiles_y) * (2 * X_TY);
-    g.x0 = tx * (2 * X_TX);
+    g.y0 = (t % a.tiles_y) * (2 * TY);
+    g.x0 = tx * (2 * TX);
     g.b = t / a.tiles_y;
     return g;
   };
@@ -471,9 +478,9 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       const int e = k * 64 + lane;
-      const int rr = e / X_RC, c = e - rr * X_RC;
+      const int rr = e / RC, c = e - rr * RC;
       const int gy = g.y0 - 1 + rr, gx = g.x0 - 1 + c;
-      const bool ok = e < X_RR * X_RC && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const bool ok = e < RR * RC && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       dma_off[k] = ok ? (gy * a.W + gx) * 4 : 0x40000000;
     }
   };
@@ -489,13 +496,13 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     }
   };
   float dreg[16];
-  const int r_lane = (2 * (mytile / X_TX)) * X_RC + 2 * (mytile % X_TX);
+  const int r_lane = (2 * (mytile / TX)) * RC + 2 * (mytile % TX);
   auto read_patch = [&](int kc) {
     const float* rp = rs + kc * X_RCH + r_lane;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      const float2 lo = *reinterpret_cast<const float2*>(rp + rr * X_RC);
-      const float2 hi = *reinterpret_cast<const float2*>(rp + rr * X_RC + 2);
+      const float2 lo = *reinterpret_cast<const float2*>(rp + rr * RC);
+      const float2 hi = *reinterpret_cast<const float2*>(rp + rr * RC + 2);
       dreg[rr * 4 + 0] = lo.x; dreg[rr * 4 + 1] = lo.y; dreg[rr * 4 + 2] = hi.x; dreg[rr * 4 + 3] = hi.y;
     }
   };
@@ -643,7 +650,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
         }
       __syncthreads();
       const int T = tg * 32 + etile;
-      const int oy = cur_g.y0 + 2 * (T / X_TX), ox = cur_g.x0 + 2 * (T % X_TX);
+      const int oy = cur_g.y0 + 2 * (T / TX), ox = cur_g.x0 + 2 * (T % TX);
       if (oy < a.H && ox < a.W) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -696,6 +703,34 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
 }
 
 bool x_small(const ConvArgs& a) { return a.W < 32 || a.dil > 1; }
+// undilated images of up to 16 x 16 pixels with enough (image, channel tile) pairs to fill the chip: the persistent
+// LDS-DMA kernel with an 8 x 8 tile block per image
+bool x_small_dma(const ConvArgs& a) {
+  return a.dil == 1 && a.W <= 16 && a.H <= 16 && a.W % 2 == 0 && a.H % 2 == 0 && a.Cin >= 2 * X_KC &&
+         (int64_t)a.B * (a.Cout / X_CO) >= 160;
+}
+
+int wino_persist() {                             // IPDM_WBX3_PERSIST=0: one workgroup per tile (tuning / fallback)
+  static int persist = -1;
+  if (persist < 0) {
+    const char* e = getenv("IPDM_WBX3_PERSIST");
+    persist = e ? atoi(e) : 1;
+  }
+  return persist;
+}
+
+int cus_per_xcd() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8)
+      n = v / 8;
+    else
+      n = 32;                                    // MI355X: 256 CUs in 8 XCDs
+  }
+  return n;
+}
 
 }  // namespace
 
@@ -710,7 +745,11 @@ bool wino_bx3_ok(const ConvArgs& a, int ks) {
 
 int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
   const bool small = x_small(a);
-  if (small) {
+  const bool small_dma = small && wino_persist() && x_small_dma(a);
+  if (small_dma) {
+    a.tiles_x = (a.W + 15) / 16;
+    a.tiles_y = (a.H + 15) / 16;
+  } else if (small) {
     a.tiles_x = ((a.H * a.W) / 4 + X_TILES - 1) / X_TILES;
     a.tiles_y = 1;
   } else {
@@ -722,37 +761,24 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
+    const void* kernels[] = {reinterpret_cast<const void*>(conv_wino_bx3_kernel<false>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_kernel<true>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true>)};
+    for (const void* k : kernels) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS_BYTES);
+      if (e != hipSuccess) return (int)e;
+    }
     attr_set = true;
   }
-  static int persist = -1;                       // IPDM_WBX3_PERSIST=0: one workgroup per tile (tuning / fallback)
-  if (persist < 0) {
-    const char* e = getenv("IPDM_WBX3_PERSIST");
-    persist = e ? atoi(e) : 1;
-  }
-  if (small) {
+  const int per_xcd = (int)((nblk + 7) / 8);
+  const int S = per_xcd < cus_per_xcd() ? per_xcd : cus_per_xcd();    // one 128+24 KiB workgroup per CU
+  if (small_dma) {
+    hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<8, 8, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+  } else if (small) {
     hipLaunchKernelGGL(conv_wino_bx3_kernel<true>, dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
-  } else if (persist && a.Cin >= 2 * X_KC) {
-    static int n_cu = 0;
-    if (!n_cu) {
-      int dev = 0, v = 0;
-      if (hipGetDevice(&dev) == hipSuccess &&
-          hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8)
-        n_cu = v;
-      else
-        n_cu = 256;                                            // MI355X
-    }
-    const int per_xcd = (int)((nblk + 7) / 8);
-    const int S = per_xcd < n_cu / 8 ? per_xcd : n_cu / 8;       // one 128+24 KiB workgroup per CU
-    hipLaunchKernelGGL(conv_wino_bx3_wide_kernel, dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+  } else if (wino_persist() && a.Cin >= 2 * X_KC) {
+    hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
   } else {
     hipLaunchKernelGGL(conv_wino_bx3_kernel<false>, dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
   }

@@ -549,7 +549,10 @@ def wino_bx3_pays(Cin, Cout, H, W, dilation=1, B=1):
     split-bf16 kernel wherever it is eligible, except on undilated images of 16 pixels or less across (a single
     64-tile workgroup per image and channel tile leaves most of the chip idle)"""
     if W <= 16 and dilation == 1:
-        return False
+        # one 8x8-tile workgroup per (image, channel tile): pays once those pairs fill the chip (512 -> 512 at B = 28:
+        # 224 pairs); with fewer the direct kernel's finer tiles win
+        if H > 16 or B * (Cout // 64) < 160 or Cin < 32:
+            return False
     if B * Cin * H * W * 4 >= (0x1fffffff if (W < 32 or dilation > 1) else 0x3fffffff):   # buffer-descriptor reach
         return False
     return conv_wino_bx3_supported(Cin, Cout, H, W, dilation)
