@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--samples-rank0", type=int, default=14)
     ap.add_argument("--samples-other", type=int, default=13)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the fp32-MFMA comparison measurement")
     ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--no-graph", action="store_true")
     return ap.parse_args()
@@ -264,7 +265,7 @@ def main():
                 "winograd_launches": n_wino, "executed_mfma_tflops": executed / (conv_ms * 1e-3) / 1e12,
                 "executed_mfma_frac": executed / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             }, **common)
-        if world == 1 and not args.full and ops.CONV_IMPL == "bx3":
+        if world == 1 and not args.full and not args.no_alt and ops.CONV_IMPL == "bx3":
             # the same iteration through the exact-fp32-MFMA kernel family (conv_mfma_kernel + fp32 Winograd),
             # reported beside the headline so that the split-bf16 result can be judged against it
             try:

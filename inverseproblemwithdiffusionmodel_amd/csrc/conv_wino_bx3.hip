@@ -706,8 +706,13 @@ bool x_small(const ConvArgs& a) { return a.W < 32 || a.dil > 1; }
 // undilated images of up to 16 x 16 pixels with enough (image, channel tile) pairs to fill the chip: the persistent
 // LDS-DMA kernel with an 8 x 8 tile block per image
 bool x_small_dma(const ConvArgs& a) {
+  static int min_pairs = -1;                     // IPDM_WBX3_SMALL_MIN: tuning aid
+  if (min_pairs < 0) {
+    const char* e = getenv("IPDM_WBX3_SMALL_MIN");
+    min_pairs = e ? atoi(e) : 160;
+  }
   return a.dil == 1 && a.W <= 16 && a.H <= 16 && a.W % 2 == 0 && a.H % 2 == 0 && a.Cin >= 2 * X_KC &&
-         (int64_t)a.B * (a.Cout / X_CO) >= 160;
+         (int64_t)a.B * (a.Cout / X_CO) >= min_pairs;
 }
 
 int wino_persist() {                             // IPDM_WBX3_PERSIST=0: one workgroup per tile (tuning / fallback)
