@@ -241,6 +241,16 @@ int ipdm_conv3d_bx3_f32(const float* x, const void* packed, const float* bias, c
                         const float* residual, float* out, float* out_act, int act_out,
                         int B, int Cin, int Cout, int D, int H, int W, int k, int dilation, void* stream);
 
+/* Split-K form of the two calls above for shapes whose tiles alone leave most of the chip idle (small images at
+ * small batch): ipdm_conv_bx3_splitk returns how many K parts pay (1 = use the plain call); with ksplit > 1 the parts
+ * write raw partial sums to `work` (ksplit * B * Cout * D * H * W floats) and a second pass adds them in fixed order
+ * (deterministic) together with bias / residual / activation.  volume: 0 = 2-D weights (D = 1), 1 = 3-D weights. */
+int ipdm_conv_bx3_splitk(int B, int D, int Cin, int Cout, int H, int W, int k, int dilation);
+int ipdm_conv_bx3_splitk_f32(const float* x, const void* packed, const float* bias, const float* coef, int act,
+                             const float* residual, float* out, float* out_act, int act_out,
+                             int B, int Cin, int Cout, int D, int H, int W, int k, int dilation, int volume, int ksplit,
+                             float* work, void* stream);
+
 /* Winograd F(2x2,3x3) with split-bf16 operands (3x3, Cin % 16 == 0, Cout % 64 == 0, see ..._supported): the same
  * call sites and output options as ipdm_conv2d_wino_f32; weights transformed, split and laid out once per layer into
  * a blob of ipdm_conv_wino_bx3_weight_bytes(Cout, Cin) bytes. */

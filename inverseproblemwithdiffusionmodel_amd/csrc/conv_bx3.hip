@@ -27,6 +27,8 @@
 
 namespace ipdm_conv {
 
+constexpr int BX3_KG = 8;       // K chunks (of 16 input channels) per accumulation group of the 16-pixel configurations
+
 template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS>
 struct BxCfg {
   static constexpr int TAPS = KS * KS;
@@ -46,7 +48,7 @@ struct BxCfg {
 };
 
 template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS, bool FAST>
-__global__ __launch_bounds__(256, (NCT * NPT <= 2 ? 4 : 2)) void conv_bx3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
   using C = BxCfg<NCT, NPT, WCO, WPX, PW, DMAX, KS>;
   static_assert(WCO * WPX == 4, "four waves per workgroup");
   extern __shared__ __align__(16) uint4 lds4[];
@@ -59,6 +61,8 @@ __global__ __launch_bounds__(256, (NCT * NPT <= 2 ? 4 : 2)) void conv_bx3_kernel
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, slot = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
+  const int ks = bid % a.ksplit;                 // split-K part (fastest: the parts of a tile share its input in L2)
+  bid /= a.ksplit;
   const int co_tile = bid % a.co_tiles;
   int t = bid / a.co_tiles;
   const int tx = t % a.tiles_x;
@@ -86,6 +90,16 @@ __global__ __launch_bounds__(256, (NCT * NPT <= 2 ? 4 : 2)) void conv_bx3_kernel
     n_kz = 1 + (lo ? 1 : 0) + (hi ? 1 : 0);
   }
   const int n_chunks = n_cc * n_kz;
+  // Split-K (16-pixel tile configurations only).  The K chunks are summed in GROUPS of BX3_KG: every group starts
+  // from a zero accumulator and the group sums are added in order.  With ksplit == 1 the workgroup walks all groups
+  // itself; with ksplit == number of groups each workgroup computes ONE group and the reduce pass adds them in the
+  // same order -- bit-identical results either way, so the choice (which depends on how many tiles the batch
+  // provides) never changes a sample's value.  An empty share (3-D border slices) writes zeros.
+  int c_begin = 0, c_end = n_chunks;
+  if (a.ksplit > 1) {
+    c_begin = ks * BX3_KG < n_chunks ? ks * BX3_KG : n_chunks;
+    c_end = c_begin + BX3_KG < n_chunks ? c_begin + BX3_KG : n_chunks;
+  }
 
   // ---- B operand read offsets (16-byte units inside a stage) ----
   int b_base[NPT];
@@ -203,11 +217,21 @@ __global__ __launch_bounds__(256, (NCT * NPT <= 2 ? 4 : 2)) void conv_bx3_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
+  f32x16 tot[PW == 16 ? NCT : 1][PW == 16 ? NPT : 1];       // group sums added in order (16-pixel configurations)
+  if constexpr (PW == 16) {
+#pragma unroll
+    for (int m = 0; m < NCT; ++m)
+#pragma unroll
+      for (int n = 0; n < NPT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[m][n][r] = 0.f;
+  }
   bf16x8 afr[2][NCT][3];
   bf16x8 bfr[2][3];
-  load_A(afr[0], a_chunk_ptr(0), 0);
-  load_chunk(0);
-  store_chunk(lds4, 0);
+  const int c_first = c_begin < n_chunks ? c_begin : n_chunks - 1;   // empty share: stage a valid chunk, use none
+  load_A(afr[0], a_chunk_ptr(c_first), 0);
+  load_chunk(c_first);
+  store_chunk(lds4, c_first);
   __syncthreads();
 
   if (a.dbg) t1 = __builtin_amdgcn_s_memtime();
@@ -223,10 +247,10 @@ __global__ __launch_bounds__(256, (NCT * NPT <= 2 ? 4 : 2)) void conv_bx3_kernel
     fr[2] = __builtin_bit_cast(bf16x8, bp[4 * C::PLANE]);
   };
 
-  for (int ch = 0; ch < n_chunks; ++ch) {
-    const uint4* cur = lds4 + (ch & 1) * C::STAGE;
-    uint4* nxt = lds4 + ((ch + 1) & 1) * C::STAGE;
-    const bool more = ch + 1 < n_chunks;
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    const uint4* cur = lds4 + ((ch - c_begin) & 1) * C::STAGE;
+    uint4* nxt = lds4 + ((ch - c_begin + 1) & 1) * C::STAGE;
+    const bool more = ch + 1 < c_end;
     const uint4* a_cur = a_chunk_ptr(ch);
     const uint4* a_nxt = a_chunk_ptr(more ? ch + 1 : ch);
     if (more) load_chunk(ch + 1);
@@ -266,6 +290,19 @@ __global__ __launch_bounds__(256, (NCT * NPT <= 2 ? 4 : 2)) void conv_bx3_kernel
 #pragma unroll
         for (int s = 0; s < 3; ++s) afr[0][m][s] = afr[1][m][s];
     }
+    if constexpr (PW == 16) {
+      if (((ch + 1) % BX3_KG) == 0 || !more) {     // end of an accumulation group (uniform)
+#pragma unroll
+        for (int m = 0; m < NCT; ++m)
+#pragma unroll
+          for (int n = 0; n < NPT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              tot[m][n][r] += acc[m][n][r];
+              acc[m][n][r] = 0.f;
+            }
+      }
+    }
     if (more) store_chunk(nxt, ch + 1);
     __syncthreads();
   }
@@ -287,7 +324,13 @@ __global__ __launch_bounds__(256, (NCT * NPT <= 2 ? 4 : 2)) void conv_bx3_kernel
         const int co = co0 + (wco * NCT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (co < a.Cout) {
           const size_t o = (((size_t)b * a.Cout + co) * a.D + z) * HW + (size_t)gy * a.W + gx;
-          float v = acc[m][n][r];
+          float v;
+          if constexpr (PW == 16) v = tot[m][n][r];
+          else v = acc[m][n][r];
+          if (a.ksplit > 1) {                    // raw partial sum; bias / residual / activation in the reduce pass
+            a.partial[(size_t)ks * a.B * a.Cout * cs + o] = v;
+            continue;
+          }
           if (a.bias) v += a.bias[co];
           if (a.residual) v += a.residual[o];
           if (a.out) a.out[o] = v;
@@ -312,7 +355,7 @@ int launch_bx3(ConvArgs a, hipStream_t s) {
   a.tiles_x = (a.W + PW - 1) / PW;
   a.tiles_y = (a.H + C::PH - 1) / C::PH;
   a.co_tiles = (a.Cout + C::CO_T - 1) / C::CO_T;
-  const int64_t nblk = (int64_t)a.B * a.D * a.tiles_x * a.tiles_y * a.co_tiles;
+  const int64_t nblk = (int64_t)a.B * a.D * a.tiles_x * a.tiles_y * a.co_tiles * a.ksplit;
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
   auto kern = conv_bx3_kernel<NCT, NPT, WCO, WPX, PW, DMAX, KS, FAST>;
   static bool attr_set = false;
@@ -351,17 +394,47 @@ int conv_bx3_dispatch(const ConvArgs& a, int ks, hipStream_t s) {
   const int f = bx3_forced_cfg();
   if (a.W <= 16) {
     if (a.dil > 1 && ks == 3) return launch_bx3_cfg<1, 2, 2, 2, 16, 4>(a, ks, s);    // 64 co x (8 x 16) px
-    if (f == 11) return launch_bx3_cfg<1, 1, 1, 4, 16, 1>(a, ks, s);                 // 32 co x (8 x 16) px
-    if (f == 12) return launch_bx3_cfg<1, 2, 1, 4, 16, 1>(a, ks, s);                 // 32 co x (16 x 16) px
-    if (f == 13) return launch_bx3_cfg<2, 2, 2, 2, 16, 1>(a, ks, s);                 // 128 co x (8 x 16) px
     return launch_bx3_cfg<1, 2, 2, 2, 16, 1>(a, ks, s);
   }
   if (a.dil > 1 && ks == 3) return launch_bx3_cfg<1, 4, 2, 2, 32, 4>(a, ks, s);
   if (f == 1) return launch_bx3_cfg<1, 2, 1, 4, 32, 1>(a, ks, s);                    // 32 co x 256 px
   if (f == 2) return launch_bx3_cfg<2, 2, 2, 2, 32, 1>(a, ks, s);                    // 128 co x 128 px
-  if (f == 3) return launch_bx3_cfg<1, 2, 2, 2, 32, 1>(a, ks, s);                    // 64 co x 128 px, 4 workgroups / CU
   if (a.Cout <= 32) return launch_bx3_cfg<1, 2, 1, 4, 32, 1>(a, ks, s);
   return launch_bx3_cfg<1, 4, 2, 2, 32, 1>(a, ks, s);                                // 64 co x (8 x 32) px
+}
+
+// split-K second pass: out = bias + sum_s partial[s] (fixed order: deterministic) + residual; out_act = act(out)
+__global__ __launch_bounds__(256) void bx3_splitk_reduce_kernel(const float* __restrict__ partial, int ksplit,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ residual, float* out,
+                                                                float* out_act, int act_out, int Cout, int64_t plane,
+                                                                int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    float v = partial[i];
+    for (int s = 1; s < ksplit; ++s) v += partial[(size_t)s * total + i];
+    if (bias) v += bias[(i / plane) % Cout];
+    if (residual) v += residual[i];
+    if (out) out[i] = v;
+    if (out_act) out_act[i] = act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, act_out);
+  }
+}
+
+// Split-K pays only when the tiles alone leave most of the chip idle (small images at small batch).  It is offered
+// for the 16-pixel tile configurations, whose accumulation is grouped (BX3_KG chunks): the answer is either 1 or the
+// number of groups, and both give bit-identical results.
+int bx3_choose_ksplit(int B, int D, int Cin, int Cout, int H, int W, int k, int dil) {
+  static int forced = -2;                        // IPDM_BX3_KSPLIT=0: never split, =1: split whenever allowed
+  if (forced == -2) {
+    const char* e = getenv("IPDM_BX3_KSPLIT");
+    forced = e ? atoi(e) : -1;
+  }
+  if (W > 16 || forced == 0) return 1;
+  const int64_t tiles = (int64_t)B * D * ((H + 7) / 8) * ((Cout + 63) / 64);
+  const int n_chunks = ((Cin + 15) / 16) * (D > 1 && k == 3 ? 3 : 1);
+  const int n_groups = (n_chunks + BX3_KG - 1) / BX3_KG;
+  if (n_groups < 2) return 1;
+  if (forced == 1) return n_groups;
+  return tiles <= 320 ? n_groups : 1;            // measured at B = 28 (224 tiles of 256 -> 256 @16^2): -0.6 ms per iteration
 }
 
 __global__ __launch_bounds__(256) void bx3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
@@ -419,6 +492,34 @@ extern "C" int ipdm_conv3d_bx3_f32(const float* x, const void* wq, const float* 
   a.D = D; a.kd = k;
   a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
   return conv_bx3_dispatch(a, k, ipdm_stream(stream));
+}
+
+extern "C" int ipdm_conv_bx3_splitk(int B, int D, int Cin, int Cout, int H, int W, int k, int dilation) {
+  return bx3_choose_ksplit(B, D, Cin, Cout, H, W, k, dilation);
+}
+
+// split-K form: `work` holds ksplit * B * Cout * D * H * W floats (ksplit from ipdm_conv_bx3_splitk, > 1);
+// volume = 0: 2-D convolution (D must be 1), volume = 1: 3-D convolution with 27- / 1-tap weights
+extern "C" int ipdm_conv_bx3_splitk_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
+                                        const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
+                                        int Cout, int D, int H, int W, int k, int dilation, int volume, int ksplit,
+                                        float* work, void* stream) {
+  IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0 && (k == 1 || k == 3) && dilation >= 1);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && wq && work && ksplit > 1 && (out || out_act) && x != out && x != out_act);
+  if (k == 3 && dilation > 4) return IPDM_EUNSUPPORTED;
+  ConvArgs a;
+  a.x = x; a.wt = (const float*)wq; a.bias = nullptr; a.coef = coef; a.residual = nullptr; a.out = nullptr; a.out_act = nullptr;
+  a.act_out = IPDM_ACT_NONE; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = k == 3 ? dilation : 1; a.act = act;
+  a.D = D; a.kd = volume ? k : 1;             // volume: the weights carry depth taps (ipdm_conv3d_bx3_f32 semantics)
+  a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = nullptr;
+  a.ksplit = ksplit; a.partial = work;
+  int rc = conv_bx3_dispatch(a, k, ipdm_stream(stream));
+  if (rc != IPDM_OK) return rc;
+  const int64_t plane = (int64_t)D * H * W, total = (int64_t)B * Cout * plane;
+  hipLaunchKernelGGL(bx3_splitk_reduce_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, ipdm_stream(stream), work, ksplit,
+                     bias, residual, out, out_act, act_out, Cout, (long long)plane, (long long)total);
+  return ipdm_launch_status();
 }
 
 extern "C" int ipdm_conv2d_bx3_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,

@@ -494,11 +494,18 @@ def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=
         e0.record()
     if vol:
         B, Cin, D, H, W = x.shape
-        call("ipdm_conv3d_bx3_f32", _ptr(x), _ptr(wq.blob), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
-             _ptr(out_act), act_out, B, Cin, wq.Cout, D, H, W, k, dilation, _stream())
     else:
         B, Cin, H, W = x.shape
         D = 1
+    ksplit = _lib.lib.ipdm_conv_bx3_splitk(B, D, Cin, wq.Cout, H, W, k, dilation) if B else 1
+    if ksplit > 1:        # too few tiles to fill the chip: deal the K loop to several workgroups per tile
+        work = torch.empty((ksplit,) + shape, dtype=torch.float32, device=x.device)
+        call("ipdm_conv_bx3_splitk_f32", _ptr(x), _ptr(wq.blob), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
+             _ptr(out_act), act_out, B, Cin, wq.Cout, D, H, W, k, dilation, int(vol), ksplit, _ptr(work), _stream())
+    elif vol:
+        call("ipdm_conv3d_bx3_f32", _ptr(x), _ptr(wq.blob), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
+             _ptr(out_act), act_out, B, Cin, wq.Cout, D, H, W, k, dilation, _stream())
+    else:
         call("ipdm_conv2d_bx3_f32", _ptr(x), _ptr(wq.blob), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
              _ptr(out_act), act_out, B, Cin, wq.Cout, H, W, k, dilation, _stream())
     if CONV_TRACE is not None:
