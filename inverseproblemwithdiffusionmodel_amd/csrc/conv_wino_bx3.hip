@@ -702,6 +702,333 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   }
 }
 
+
+// ---- 128 output channels x 32 tiles per workgroup (Cout % 128 == 0) -------------------------------------------------
+// Same persistent scheme, different split of the 128 accumulator registers: a wave still owns two positions, but
+// for FOUR channel tiles (128 channels) of ONE 32-tile group.  Every split V fragment now feeds 24 MFMAs instead of 12,
+// so the operand split -- the bulk of the VALU work that made the 64x64 form issue-bound -- halves per MFMA, the
+// transform / LDS / DMA work per MFMA halves too (32 tiles per 128 channels), and the input region is fetched once
+// instead of once per 64-channel tile.  The price is the A side: 24 instead of 12 one-KiB fragment loads per wave
+// and chunk (L2 -> CU at about half of its rate).  LDS: two 32 KiB V stages, a 16 KiB raw stage and a separate 64 KiB
+// exchange buffer for the epilogue (four rounds, one channel tile each), 144 KiB.
+// Activations are streamed (each byte read or written once per launch) while the Winograd weights are re-read by every
+// workgroup: the input DMA, the residual loads and the output stores carry the non-temporal policy so that they do
+// not push the weights out of L2.  -DIPDM_NO_NT builds the default-policy variant (A/B).
+#ifdef IPDM_NO_NT
+#define IPDM_NT_AUX 0
+#define IPDM_NT_LOAD2(p) (*reinterpret_cast<const float2*>(p))
+#define IPDM_NT_STORE2(p, x, y) (*reinterpret_cast<float2*>(p) = make_float2((x), (y)))
+#else
+#define IPDM_NT_AUX 2
+typedef float ipdm_f2v __attribute__((ext_vector_type(2)));
+#define IPDM_NT_LOAD2(p) ([&] { const ipdm_f2v t_ = __builtin_nontemporal_load(reinterpret_cast<const ipdm_f2v*>(p)); return make_float2(t_.x, t_.y); }())
+#define IPDM_NT_STORE2(p, x, y) __builtin_nontemporal_store(ipdm_f2v{(x), (y)}, reinterpret_cast<ipdm_f2v*>(p))
+#endif
+constexpr int Y_TILES = 32;
+constexpr int Y_V_ELEMS = 16 * X_KC * Y_TILES;                 // 8192 floats per stage
+constexpr int Y_RCH = 256;                                     // raw floats per channel (4 wave-instructions)
+constexpr int Y_R_ELEMS = X_KC * Y_RCH;
+constexpr int Y_M_ELEMS = 16 * 32 * Y_TILES;                   // 16384 floats
+constexpr size_t Y_LDS_BYTES = (2 * (size_t)Y_V_ELEMS + Y_R_ELEMS + Y_M_ELEMS) * sizeof(float);
+
+template <int TX, int TY, bool CO_MAJOR>
+__global__ __launch_bounds__(512) void conv_wino_bx3_c128_kernel(ConvArgs a, int total_tiles) {
+  static_assert(TX * TY == Y_TILES, "32 tiles per workgroup");
+  constexpr int RC = 2 * TX + 2, RR = 2 * TY + 2;             // raw region: 34 x 6 (wide) or 18 x 10 (16-pixel images)
+  static_assert(RC * RR <= Y_RCH, "raw region fits its LDS slot");
+  extern __shared__ __align__(16) float lds[];
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  if (a.dbg) t0 = __builtin_amdgcn_s_memtime();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, j = lane & 31;
+  const int HW = a.H * a.W;
+  const int n_cc = a.Cin / X_KC, n_ct = a.Cout / 32;
+  const int n_chunks = n_cc;                                  // >= 2 (launcher)
+  const int p0 = 2 * wave;
+  const int co_tiles = a.Cout / 128;
+
+  const int S = gridDim.x / 8;
+  const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+  const int q = total_tiles / 8, r8 = total_tiles % 8;
+  const int x_start = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+  const int x_end = x_start + q + (xcd < r8 ? 1 : 0);
+  int tile = x_start + slot;
+  if (tile >= x_end) return;
+
+  struct Geo { int b, y0, x0, co_tile; };
+  auto geo_of = [&](int L) {
+    Geo g;
+    const int n_px = total_tiles / co_tiles;
+    g.co_tile = CO_MAJOR ? L / n_px : L % co_tiles;
+    int t = CO_MAJOR ? L % n_px : L / co_tiles;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    g.y0 = (t % a.tiles_y) * (2 * TY);
+    g.x0 = tx * (2 * TX);
+    g.b = t / a.tiles_y;
+    return g;
+  };
+
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((size_t)a.B * a.Cin * HW * 4), 0x00020000);
+  float* const rs = lds + 2 * Y_V_ELEMS;
+  float* const ms = rs + Y_R_ELEMS;                           // M[pos 16][co 32][tile 32]
+
+  // raw stage by LDS-DMA: wave w brings in channels 2w, 2w+1 (4 x 64 floats each)
+  int dma_off[4];
+  int dma_b = 0;
+  auto set_dma_geo = [&](const Geo& g) {
+    dma_b = g.b;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = k * 64 + lane;
+      const int rr = e / RC, c = e - rr * RC;
+      const int gy = g.y0 - 1 + rr, gx = g.x0 - 1 + c;
+      const bool ok = e < RR * RC && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      dma_off[k] = ok ? (gy * a.W + gx) * 4 : 0x40000000;
+    }
+  };
+  auto issue_dma = [&](int chunk) {
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl) {
+      const int kc = 2 * wave + cl;
+      const int soff = (int)(((size_t)dma_b * a.Cin + chunk * X_KC + kc) * HW * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(rs + kc * Y_RCH + k * 64), 4,
+                                                 dma_off[k], soff, 0, IPDM_NT_AUX);
+    }
+  };
+  // staging: this thread transforms tile `mytile` of channel `mykc` = 2w + (lane >> 5) of every chunk
+  const int mytile = lane & 31, mykc = 2 * wave + (lane >> 5);
+  float dreg[16];
+  const int r_lane = mykc * Y_RCH + (2 * (mytile / TX)) * RC + 2 * (mytile % TX);
+  auto read_patch = [&]() {
+    const float* rp = rs + r_lane;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const float2 lo = *reinterpret_cast<const float2*>(rp + rr * RC);
+      const float2 hi = *reinterpret_cast<const float2*>(rp + rr * RC + 2);
+      dreg[rr * 4 + 0] = lo.x; dreg[rr * 4 + 1] = lo.y; dreg[rr * 4 + 2] = hi.x; dreg[rr * 4 + 3] = hi.y;
+    }
+  };
+  auto store_patch = [&](float* st) {                         // Vs[pos][kc 16][tile 32]
+    const float(&dd)[16] = dreg;
+    float tmp[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      tmp[0 * 4 + c] = dd[0 * 4 + c] - dd[2 * 4 + c];
+      tmp[1 * 4 + c] = dd[1 * 4 + c] + dd[2 * 4 + c];
+      tmp[2 * 4 + c] = dd[2 * 4 + c] - dd[1 * 4 + c];
+      tmp[3 * 4 + c] = dd[1 * 4 + c] - dd[3 * 4 + c];
+    }
+    float* vs = st + mykc * Y_TILES + mytile;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      vs[(rr * 4 + 0) * X_KC * Y_TILES] = tmp[rr * 4 + 0] - tmp[rr * 4 + 2];
+      vs[(rr * 4 + 1) * X_KC * Y_TILES] = tmp[rr * 4 + 1] + tmp[rr * 4 + 2];
+      vs[(rr * 4 + 2) * X_KC * Y_TILES] = tmp[rr * 4 + 2] - tmp[rr * 4 + 1];
+      vs[(rr * 4 + 3) * X_KC * Y_TILES] = tmp[rr * 4 + 1] - tmp[rr * 4 + 3];
+    }
+  };
+
+  // A fragments of (position p, chunk cc, channel tiles 4*co_tile + 2*cp, +1)
+  const uint4* wq = reinterpret_cast<const uint4*>(a.wt);
+  const size_t pos_stride = (size_t)n_cc * n_ct * 192;
+  auto load_A = [&](bf16x8 (&fr)[2][3], int p, int cc, int co_tile, int cp) {
+    const uint4* base = wq + (size_t)p * pos_stride + ((size_t)cc * n_ct + co_tile * 4 + cp * 2) * 192 + lane;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) fr[c][s] = __builtin_bit_cast(bf16x8, base[c * 192 + s * 64]);
+  };
+  const int b_lane = (8 * h) * Y_TILES + j;
+  auto load_B = [&](float (&raw)[8], const float* cur, int pi) {
+    const float* bp = cur + (p0 + pi) * (X_KC * Y_TILES) + b_lane;
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) raw[qq] = bp[qq * Y_TILES];
+  };
+
+  f32x16 acc[2][4];                                           // [position][channel tile]
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) acc[i >> 2][i & 3][rr] = 0.f;
+  };
+  zero_acc();
+
+  // ---- prologue of the first tile ----
+  Geo cur_g = geo_of(tile);
+  bf16x8 afr[2][2][3];
+  load_A(afr[0], p0, 0, cur_g.co_tile, 0);
+  set_dma_geo(cur_g);
+  issue_dma(0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  read_patch();
+  store_patch(lds);
+  __syncthreads();
+  issue_dma(1);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (a.dbg) t1 = __builtin_amdgcn_s_memtime();
+
+  int g = 0;
+  while (true) {
+    const int next_tile = tile + S;
+    const bool has_next = next_tile < x_end;
+    const Geo next_g = geo_of(has_next ? next_tile : tile);
+    for (int ch = 0; ch < n_chunks; ++ch, ++g) {
+      const float* cur = lds + (g & 1) * Y_V_ELEMS;
+      float* nxt = lds + ((g + 1) & 1) * Y_V_ELEMS;
+      const bool dma_next = ch + 2 >= n_chunks;
+      const int dma_chunk = dma_next ? ch + 2 - n_chunks : ch + 2;
+      if (ch + 2 == n_chunks) set_dma_geo(next_g);
+      const bool a_next = ch + 1 >= n_chunks;
+      const int a_chunk = a_next ? 0 : ch + 1;
+      const int a_cot = a_next ? next_g.co_tile : cur_g.co_tile;
+      bf16x8 bs[2][3];
+      float raw[8];
+      load_B(raw, cur, 0);
+#if defined(IPDM_PROBE) && (IPDM_PROBE & 1)
+      { uint4 u0 = make_uint4(__float_as_uint(raw[0]), __float_as_uint(raw[1]), __float_as_uint(raw[2]), __float_as_uint(raw[3]));
+        uint4 u1 = make_uint4(__float_as_uint(raw[4]), __float_as_uint(raw[5]), __float_as_uint(raw[6]), __float_as_uint(raw[7]));
+        bs[0][0] = __builtin_bit_cast(bf16x8, u0); bs[0][1] = __builtin_bit_cast(bf16x8, u1); bs[0][2] = bs[0][0]; }
+#else
+      split3(raw, bs[0][0], bs[0][1], bs[0][2]);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      // four steps (position pi, channel-tile pair cp) of 12 MFMAs; A fragments one step ahead
+      static_for<4>([&](auto sc) {
+        constexpr int st = decltype(sc)::value;
+        constexpr int pi = st >> 1, cp = st & 1;
+        if constexpr (st == 0) {
+#if !(defined(IPDM_PROBE) && (IPDM_PROBE & 8))
+          load_A(afr[1], p0, ch, cur_g.co_tile, 1);
+#endif
+#if !(defined(IPDM_PROBE) && (IPDM_PROBE & 2))
+          read_patch();
+          store_patch(nxt);
+#endif
+        }
+        if constexpr (st == 1) {
+#if !(defined(IPDM_PROBE) && (IPDM_PROBE & 8))
+          load_A(afr[0], p0 + 1, ch, cur_g.co_tile, 0);
+#endif
+#if !(defined(IPDM_PROBE) && (IPDM_PROBE & 4))
+          issue_dma(dma_chunk);
+#endif
+          load_B(raw, cur, 1);
+#if defined(IPDM_PROBE) && (IPDM_PROBE & 1)
+          { uint4 u0 = make_uint4(__float_as_uint(raw[0]), __float_as_uint(raw[1]), __float_as_uint(raw[2]), __float_as_uint(raw[3]));
+            uint4 u1 = make_uint4(__float_as_uint(raw[4]), __float_as_uint(raw[5]), __float_as_uint(raw[6]), __float_as_uint(raw[7]));
+            bs[1][0] = __builtin_bit_cast(bf16x8, u0); bs[1][1] = __builtin_bit_cast(bf16x8, u1); bs[1][2] = bs[1][0]; }
+#else
+          split3(raw, bs[1][0], bs[1][1], bs[1][2]);
+#endif
+        }
+#if !(defined(IPDM_PROBE) && (IPDM_PROBE & 8))
+        if constexpr (st == 2) load_A(afr[1], p0 + 1, ch, cur_g.co_tile, 1);
+        if constexpr (st == 3) load_A(afr[0], p0, a_chunk, a_cot, 0);
+#endif
+        const bf16x8 bh = bs[pi][0], bm = bs[pi][1], bl = bs[pi][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          f32x16 v = acc[pi][cp * 2 + c];
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][c][2], bh, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][c][0], bl, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][c][1], bm, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][c][1], bh, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][c][0], bm, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][c][0], bh, v, 0, 0, 0);
+          acc[pi][cp * 2 + c] = v;
+        }
+        if constexpr (st == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // the patch reads
+        if constexpr (st == 1) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // position p0+1's V reads
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, st < 2 ? 6 : 2, 0);
+          if constexpr (st == 0) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (st == 0) __syncthreads();               // everyone has read the raw stage
+      });
+      __builtin_amdgcn_s_waitcnt(0);                          // the DMA has landed
+      __syncthreads();
+    }
+    if (a.dbg) t2 = __builtin_amdgcn_s_memtime();
+
+    // ---- epilogue: four rounds (channel tile ct) through the exchange buffer ----
+    const int etile = tid & 31, ecg = tid >> 5;               // this thread: tile, channels 2*ecg, 2*ecg+1 of the 32
+    const int co0 = cur_g.co_tile * 128;
+    const int oy = cur_g.y0 + 2 * (etile / TX), ox = cur_g.x0 + 2 * (etile % TX);
+    const bool out_ok = oy < a.H && ox < a.W;
+    static_for<4>([&](auto rc) {
+      constexpr int ct = decltype(rc)::value;
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int col = (rr & 3) + 8 * (rr >> 2) + 4 * h;
+          ms[((p0 + pi) * 32 + col) * 32 + j] = acc[pi][ct][rr];
+        }
+      __syncthreads();
+      if (out_ok) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int cl = ecg * 2 + i;
+          const int co = co0 + ct * 32 + cl;
+          float m[16];
+#pragma unroll
+          for (int p = 0; p < 16; ++p) m[p] = ms[(p * 32 + cl) * 32 + etile];
+          float tt[2][4];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            tt[0][qq] = m[0 * 4 + qq] + m[1 * 4 + qq] + m[2 * 4 + qq];
+            tt[1][qq] = m[1 * 4 + qq] - m[2 * 4 + qq] - m[3 * 4 + qq];
+          }
+          const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            float y0v = tt[ii][0] + tt[ii][1] + tt[ii][2] + bias;
+            float y1v = tt[ii][1] - tt[ii][2] - tt[ii][3] + bias;
+            const size_t o = ((size_t)cur_g.b * a.Cout + co) * HW + (size_t)(oy + ii) * a.W + ox;
+            if (a.residual) {
+              const float2 rr2 = IPDM_NT_LOAD2(a.residual + o);
+              y0v += rr2.x;
+              y1v += rr2.y;
+            }
+            if (a.out) IPDM_NT_STORE2(a.out + o, y0v, y1v);
+            if (a.out_act) {
+              const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
+              const float e1 = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
+              IPDM_NT_STORE2(a.out_act + o, e0, e1);
+            }
+          }
+        }
+      }
+      __syncthreads();
+    });
+    if (!has_next) break;
+    zero_acc();
+    tile = next_tile;
+    cur_g = next_g;
+  }
+  if (a.dbg) {
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      unsigned long long* d4 = a.dbg + (size_t)blockIdx.x * 4;
+      d4[0] = t0; d4[1] = t1; d4[2] = t2; d4[3] = t3;
+    }
+  }
+}
+
 bool x_small(const ConvArgs& a) { return a.W < 32 || a.dil > 1; }
 // undilated images of up to 16 x 16 pixels with enough (image, channel tile) pairs to fill the chip: the persistent
 // LDS-DMA kernel with an 8 x 8 tile block per image
@@ -775,6 +1102,43 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
       if (e != hipSuccess) return (int)e;
     }
     attr_set = true;
+  }
+  // IPDM_WBX3_C128=1 selects the 128-channel x 32-tile form.  Off by default: it wins 3-15 % per layer in isolation
+  // (scripts/bench_conv.py) but loses 2.7 % on the whole iteration (26.07 vs 25.37 ms, same box, alternating runs) --
+  // its doubled fragment traffic costs more clock under the sustained power limit than the halved VALU work returns.
+  static int use_c128 = -1;
+  if (use_c128 < 0) {
+    const char* e = getenv("IPDM_WBX3_C128");
+    use_c128 = e ? atoi(e) : 0;
+  }
+  if (use_c128 && wino_persist() && a.Cout % 128 == 0 && a.Cin >= 2 * X_KC && (small_dma || !small)) {
+    // 128 channels x 32 tiles per workgroup: 16 x 2 tiles (4 x 32 pixels) on wide images, 8 x 4 (8 x 16) on small ones
+    static bool attr2 = false;
+    if (!attr2) {
+      const void* ks[] = {reinterpret_cast<const void*>(conv_wino_bx3_c128_kernel<16, 2, false>),
+                          reinterpret_cast<const void*>(conv_wino_bx3_c128_kernel<8, 4, true>)};
+      for (const void* k : ks) {
+        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Y_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+      }
+      attr2 = true;
+    }
+    if (small_dma) {
+      a.tiles_x = (a.W + 15) / 16;
+      a.tiles_y = (a.H + 7) / 8;
+    } else {
+      a.tiles_x = (a.W + 31) / 32;
+      a.tiles_y = (a.H + 3) / 4;
+    }
+    const int64_t n2 = (int64_t)a.B * a.tiles_x * a.tiles_y * (a.Cout / 128);
+    if (n2 > 0x7fffffff) return IPDM_EUNSUPPORTED;
+    const int px = (int)((n2 + 7) / 8);
+    const int S2 = px < cus_per_xcd() ? px : cus_per_xcd();
+    if (small_dma)
+      hipLaunchKernelGGL((conv_wino_bx3_c128_kernel<8, 4, true>), dim3((unsigned)(8 * S2)), dim3(512), Y_LDS_BYTES, s, a, (int)n2);
+    else
+      hipLaunchKernelGGL((conv_wino_bx3_c128_kernel<16, 2, false>), dim3((unsigned)(8 * S2)), dim3(512), Y_LDS_BYTES, s, a, (int)n2);
+    return ipdm_launch_status();
   }
   const int per_xcd = (int)((nblk + 7) / 8);
   const int S = per_xcd < cus_per_xcd() ? per_xcd : cus_per_xcd();    // one 128+24 KiB workgroup per CU
