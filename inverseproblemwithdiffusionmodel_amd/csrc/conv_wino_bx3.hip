@@ -36,7 +36,7 @@ constexpr int X_V_ELEMS = 16 * X_KC * X_TILES;                   // 16384 floats
 // LDS-DMA (buffer_load ... lds: no VGPRs, hardware zero padding) and the 4x4 patches are read from there
 constexpr int X_RR = 2 * X_TY + 2, X_RC = 2 * X_TX + 2;          // 10 x 34
 constexpr int X_RCH = 384;                                       // floats per channel (6 wave-instructions of 64 lanes)
-constexpr int X_R_ELEMS = X_KC * X_RCH;
+constexpr int X_R_ELEMS = 27 * 256;                              // >= 16 x 384 (dword form) and 27 quad pieces (DMA4, 8x8 tiles)
 constexpr size_t X_LDS_BYTES = (2 * (size_t)X_V_ELEMS + X_R_ELEMS) * sizeof(float);   // 128 KiB + 24 KiB
 
 // U[p = a*4+b][co][ci] = sum_ij G[a][i] g[co][ci][i][j] G[b][j], split into three bf16 pieces, stored as MFMA
@@ -425,8 +425,16 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
 // channel tiles of a pixel tile meet in that XCD's L2) and its workgroups stride through it.
 // TX x TY tiles per workgroup: 16 x 4 (8 x 32 output pixels) for wide images, 8 x 8 (16 x 16) for 16-pixel images, whose
 // workgroups are dealt channel-tile-major (CO_MAJOR: an XCD keeps ONE channel tile's 3 MiB of Winograd weights in L2).
-template <int TX, int TY, bool CO_MAJOR>
+// DMA4 (W % 4 == 0, 16-byte aligned tensor): the raw region is fetched as 16-byte quads aligned to multiples of four
+// pixels (a quad is then entirely inside or entirely outside the image, so the range check still pads), 25-27
+// wave-instructions per chunk and workgroup instead of 96 -- an LDS-DMA instruction costs ~100 issue cycles next to
+// MFMAs, whatever its width.
+template <int TX, int TY, bool CO_MAJOR, bool DMA4>
 __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int total_tiles) {
+  constexpr int QC = TX / 2 + 2, RC4 = 4 * QC;               // quads / floats per raw row (x0-4 .. x0+2TX+3)
+  constexpr int QN = (2 * TY + 2) * QC;                       // quads per channel
+  constexpr int NI = (X_KC * QN + 63) / 64;                   // wave-instructions per chunk
+  static_assert(NI <= 32 && NI * 256 <= X_R_ELEMS, "quad image fits the raw stage");
   static_assert(TX * TY == X_TILES, "64 tiles per workgroup");
   constexpr int RC = 2 * TX + 2, RR = 2 * TY + 2;            // raw region: 34 x 10 or 18 x 18 pixels (<= X_RCH)
   static_assert(RC * RR <= X_RCH, "raw region fits its LDS slot");
@@ -470,40 +478,76 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   float* const rs = lds + 2 * X_V_ELEMS;
   const int mytile = tid & 63;
 
-  // raw stage by LDS-DMA: wave w brings in channels 2w, 2w+1 (6 x 64 floats each)
-  int dma_off[6];
+  // raw stage by LDS-DMA.  dword form: wave w brings in channels 2w, 2w+1 (6 x 64 floats each); quad form: the
+  // chunk's 16 channels are one packed image of NI x 64 quads, wave w issues pieces w, w+8, w+16, w+24
+  int dma_off[DMA4 ? 4 : 6];
   int dma_b = 0;                                              // image index the offsets belong to
   auto set_dma_geo = [&](const Geo& g) {
     dma_b = g.b;
+    if constexpr (DMA4) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const int e = k * 64 + lane;
-      const int rr = e / RC, c = e - rr * RC;
-      const int gy = g.y0 - 1 + rr, gx = g.x0 - 1 + c;
-      const bool ok = e < RR * RC && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      dma_off[k] = ok ? (gy * a.W + gx) * 4 : 0x40000000;
+      for (int k = 0; k < 4; ++k) {
+        const int e = (wave + 8 * k) * 64 + lane;
+        const int cin = e / QN, qq = e - cin * QN;
+        const int rr = qq / QC, qc = qq - rr * QC;
+        const int gy = g.y0 - 1 + rr, gx0 = g.x0 - 4 + 4 * qc;
+        const bool ok = e < X_KC * QN && gy >= 0 && gy < a.H && gx0 >= 0 && gx0 < a.W;
+        dma_off[k] = ok ? (cin * HW + gy * a.W + gx0) * 4 : 0x40000000;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int e = k * 64 + lane;
+        const int rr = e / RC, c = e - rr * RC;
+        const int gy = g.y0 - 1 + rr, gx = g.x0 - 1 + c;
+        const bool ok = e < RR * RC && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        dma_off[k] = ok ? (gy * a.W + gx) * 4 : 0x40000000;
+      }
     }
   };
   auto issue_dma = [&](int chunk) {
+    if constexpr (DMA4) {
+      const int soff = (int)(((size_t)dma_b * a.Cin + chunk * X_KC) * HW * 4);
 #pragma unroll
-    for (int cl = 0; cl < 2; ++cl) {
-      const int kc = 2 * wave + cl;
-      const int soff = (int)(((size_t)dma_b * a.Cin + chunk * X_KC + kc) * HW * 4);
+      for (int k = 0; k < 4; ++k)
+        if (wave + 8 * k < NI) {                              // wave-uniform
+#if defined(__HIP_DEVICE_COMPILE__)   // the 16-byte form only exists for gfx950: keep it out of the host pass
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(rs + (wave + 8 * k) * 256),
+                                                   16, dma_off[k], soff, 0, 0);
+#endif
+        }
+    } else {
 #pragma unroll
-      for (int k = 0; k < 6; ++k)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(rs + kc * X_RCH + k * 64), 4,
-                                                 dma_off[k], soff, 0, 0);
+      for (int cl = 0; cl < 2; ++cl) {
+        const int kc = 2 * wave + cl;
+        const int soff = (int)(((size_t)dma_b * a.Cin + chunk * X_KC + kc) * HW * 4);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(rs + kc * X_RCH + k * 64), 4,
+                                                   dma_off[k], soff, 0, 0);
+      }
     }
   };
   float dreg[16];
-  const int r_lane = (2 * (mytile / TX)) * RC + 2 * (mytile % TX);
+  const int r_lane = DMA4 ? (2 * (mytile / TX)) * RC4 + 2 * (mytile % TX) + 2 : (2 * (mytile / TX)) * RC + 2 * (mytile % TX);
   auto read_patch = [&](int kc) {
-    const float* rp = rs + kc * X_RCH + r_lane;
+    if constexpr (DMA4) {                                     // patch columns 2txl+3 .. 2txl+6 of the 4-aligned rows
+      const float* rp = rs + kc * (QN * 4) + r_lane;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const float2 lo = *reinterpret_cast<const float2*>(rp + rr * RC);
-      const float2 hi = *reinterpret_cast<const float2*>(rp + rr * RC + 2);
-      dreg[rr * 4 + 0] = lo.x; dreg[rr * 4 + 1] = lo.y; dreg[rr * 4 + 2] = hi.x; dreg[rr * 4 + 3] = hi.y;
+      for (int rr = 0; rr < 4; ++rr) {
+        const float2 q0 = *reinterpret_cast<const float2*>(rp + rr * RC4);
+        const float2 q1 = *reinterpret_cast<const float2*>(rp + rr * RC4 + 2);
+        const float2 q2 = *reinterpret_cast<const float2*>(rp + rr * RC4 + 4);
+        dreg[rr * 4 + 0] = q0.y; dreg[rr * 4 + 1] = q1.x; dreg[rr * 4 + 2] = q1.y; dreg[rr * 4 + 3] = q2.x;
+      }
+    } else {
+      const float* rp = rs + kc * X_RCH + r_lane;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float2 lo = *reinterpret_cast<const float2*>(rp + rr * RC);
+        const float2 hi = *reinterpret_cast<const float2*>(rp + rr * RC + 2);
+        dreg[rr * 4 + 0] = lo.x; dreg[rr * 4 + 1] = lo.y; dreg[rr * 4 + 2] = hi.x; dreg[rr * 4 + 3] = hi.y;
+      }
     }
   };
   auto store_patch = [&](float* st, int kc) {
@@ -1095,8 +1139,10 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
   if (!attr_set) {
     const void* kernels[] = {reinterpret_cast<const void*>(conv_wino_bx3_kernel<false>),
                              reinterpret_cast<const void*>(conv_wino_bx3_kernel<true>),
-                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false>),
-                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true>)};
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, false>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, false>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, true>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, true>)};
     for (const void* k : kernels) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS_BYTES);
       if (e != hipSuccess) return (int)e;
@@ -1142,12 +1188,24 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
   }
   const int per_xcd = (int)((nblk + 7) / 8);
   const int S = per_xcd < cus_per_xcd() ? per_xcd : cus_per_xcd();    // one 128+24 KiB workgroup per CU
+  static int dma4_ok = -1;                       // IPDM_WBX3_DMA4=0: dword LDS-DMA everywhere (tuning / fallback)
+  if (dma4_ok < 0) {
+    const char* e = getenv("IPDM_WBX3_DMA4");
+    dma4_ok = e ? atoi(e) : 1;
+  }
+  const bool dma4 = dma4_ok && a.W % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
   if (small_dma) {
-    hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<8, 8, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+    if (dma4)
+      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<8, 8, true, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+    else
+      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<8, 8, true, false>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
   } else if (small) {
     hipLaunchKernelGGL(conv_wino_bx3_kernel<true>, dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
   } else if (wino_persist() && a.Cin >= 2 * X_KC) {
-    hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+    if (dma4)
+      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+    else
+      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false, false>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
   } else {
     hipLaunchKernelGGL(conv_wino_bx3_kernel<false>, dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
   }
