@@ -531,14 +531,25 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   float dreg[16];
   const int r_lane = DMA4 ? (2 * (mytile / TX)) * RC4 + 2 * (mytile % TX) + 2 : (2 * (mytile / TX)) * RC + 2 * (mytile % TX);
   auto read_patch = [&](int kc) {
-    if constexpr (DMA4) {                                     // patch columns 2txl+3 .. 2txl+6 of the 4-aligned rows
-      const float* rp = rs + kc * (QN * 4) + r_lane;
+    if constexpr (DMA4) {
+      // patch columns 2txl+3 .. 2txl+6 of the 4-aligned rows.  A lane reads only its own aligned pair (2txl+4, 2txl+5);
+      // column 2txl+3 is the left neighbour tile's second element and 2txl+6 the right neighbour's first (lanes of a
+      // 16-lane DPP row are consecutive tiles of a tile row), the two tiles at the ends of a tile row read theirs:
+      // 8 instead of 12 LDS instructions and half the LDS bytes per patch.
+      const float* rp = rs + kc * (QN * 4) + r_lane;          // -> column 2txl+2
+      const int txl = mytile % TX;
+      const bool first = txl == 0, last = txl == TX - 1;
+      const int edge = first ? 1 : 4;                         // column 2txl+3 (first) / 2txl+6 (last); others: unused
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const float2 q0 = *reinterpret_cast<const float2*>(rp + rr * RC4);
         const float2 q1 = *reinterpret_cast<const float2*>(rp + rr * RC4 + 2);
-        const float2 q2 = *reinterpret_cast<const float2*>(rp + rr * RC4 + 4);
-        dreg[rr * 4 + 0] = q0.y; dreg[rr * 4 + 1] = q1.x; dreg[rr * 4 + 2] = q1.y; dreg[rr * 4 + 3] = q2.x;
+        const float e = rp[rr * RC4 + edge];
+        const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q1.y), 0x111, 0xf, 0xf, false));
+        const float right = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q1.x), 0x101, 0xf, 0xf, false));
+        dreg[rr * 4 + 0] = first ? e : left;
+        dreg[rr * 4 + 1] = q1.x;
+        dreg[rr * 4 + 2] = q1.y;
+        dreg[rr * 4 + 3] = last ? e : right;
       }
     } else {
       const float* rp = rs + kc * X_RCH + r_lane;
