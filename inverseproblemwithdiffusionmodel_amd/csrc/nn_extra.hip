@@ -47,6 +47,88 @@ __global__ __launch_bounds__(256) void groupnorm_coef_kernel(const float* __rest
 }
 
 // y[b][o] = bias[o] + sum_i act(x[b][i]) * W[o][i]     (torch.nn.Linear layout), one wave per output
+// GroupNorm in two register-resident passes (planes of up to 65536 elements): x is read ONCE.
+//   gn_plane_kernel<T>: one workgroup of T threads per (image, channel) plane, 16 float4 per thread:
+//       mean_c and M2_c = sum (x - mean_c)^2, parked in coef[b][c][0..1]
+//   gn_combine_kernel:  one workgroup per (image, group): equal-sized planes combine exactly as
+//       mean_g = avg(mean_c),  M2_g = sum M2_c + HW * sum (mean_c - mean_g)^2   (Chan et al.)
+// against (B x G) workgroups sweeping (C/G)*HW elements twice in groupnorm_coef_kernel (kept for larger planes).
+template <int T>
+__global__ __launch_bounds__(T) void gn_plane_kernel(const float* __restrict__ x, float* __restrict__ coef, int HW) {
+  __shared__ double red[T / 64];
+  const float* p = x + (size_t)blockIdx.x * HW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n4 = HW / 4;
+  float4 keep[16];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = tid + k * T;
+    keep[k] = i < n4 ? reinterpret_cast<const float4*>(p)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (tid + k * T < n4) s += (keep[k].x + keep[k].y) + (keep[k].z + keep[k].w);
+  double ds = ipdm_wave_sum((double)s);
+  if (lane == 0) red[wave] = ds;
+  __syncthreads();
+  double tot = 0.0;
+#pragma unroll
+  for (int w = 0; w < T / 64; ++w) tot += red[w];
+  const float mean = (float)(tot / (double)HW);
+  __syncthreads();
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (tid + k * T < n4) {
+      const float a = keep[k].x - mean, b = keep[k].y - mean, c = keep[k].z - mean, d = keep[k].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  double dq = ipdm_wave_sum((double)q);
+  if (lane == 0) red[wave] = dq;
+  __syncthreads();
+  if (tid == 0) {
+    double m2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < T / 64; ++w) m2 += red[w];
+    coef[(size_t)blockIdx.x * 3 + 0] = mean;
+    coef[(size_t)blockIdx.x * 3 + 1] = (float)m2;
+  }
+}
+
+__global__ __launch_bounds__(64) void gn_combine_kernel(const float* __restrict__ weight, const float* __restrict__ bias,
+                                                        float* __restrict__ coef, int C, int HW, int G, float eps) {
+  const int b = blockIdx.x / G, g = blockIdx.x % G;
+  const int cpg = C / G;
+  float* cg = coef + ((size_t)b * C + (size_t)g * cpg) * 3;
+  const int lane = threadIdx.x;
+  double sm = 0.0, s2 = 0.0;
+  for (int c = lane; c < cpg; c += 64) {
+    sm += (double)cg[c * 3 + 0];
+    s2 += (double)cg[c * 3 + 1];
+  }
+  sm = ipdm_wave_sum(sm);
+  s2 = ipdm_wave_sum(s2);
+  const double mean_g = sm / (double)cpg;
+  double dev = 0.0;
+  for (int c = lane; c < cpg; c += 64) {
+    const double dm = (double)cg[c * 3 + 0] - mean_g;
+    dev += dm * dm;
+  }
+  dev = ipdm_wave_sum(dev);
+  const double var = (s2 + (double)HW * dev) / ((double)cpg * (double)HW);
+  const float rstd = 1.0f / sqrtf((float)var + eps);
+  const float mg = (float)mean_g;
+  // all reads of the parked (mean_c, M2_c) are done (wave-synchronous: one wave per workgroup)
+  for (int c = lane; c < cpg; c += 64) {
+    const int ch = g * cpg + c;
+    cg[c * 3 + 0] = mg;
+    cg[c * 3 + 1] = (weight ? weight[ch] : 1.f) * rstd;
+    cg[c * 3 + 2] = bias ? bias[ch] : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ y, int B,
                                                      int In, int Out, int act) {
@@ -148,6 +230,14 @@ extern "C" int ipdm_groupnorm_coef_f32(const float* x, const float* weight, cons
   IPDM_REQUIRE(B >= 0 && C > 0 && HW > 0 && G > 0 && C % G == 0);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && coef);
+  if (HW % 4 == 0 && HW <= 65536 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    if (HW <= 16384)
+      hipLaunchKernelGGL(gn_plane_kernel<256>, dim3(B * C), dim3(256), 0, ipdm_stream(stream), x, coef, HW);
+    else
+      hipLaunchKernelGGL(gn_plane_kernel<1024>, dim3(B * C), dim3(1024), 0, ipdm_stream(stream), x, coef, HW);
+    hipLaunchKernelGGL(gn_combine_kernel, dim3(B * G), dim3(64), 0, ipdm_stream(stream), weight, bias, coef, C, HW, G, eps);
+    return ipdm_launch_status();
+  }
   hipLaunchKernelGGL(groupnorm_coef_kernel, dim3(B * G), dim3(256), 0, ipdm_stream(stream), x, weight, bias, coef, C, HW,
                      G, eps);
   return ipdm_launch_status();

@@ -129,3 +129,19 @@ def test_philox_noise_source_and_registry():
     assert sampling.get_corrector("langevin").__name__ == "LangevinCorrector"
     with pytest.raises(ValueError):
         sampling.register_predictor(name="none")(sampling.NonePredictor)
+
+
+@pytest.mark.parametrize("B,C,G,H,W", [(2, 128, 32, 256, 256), (3, 64, 16, 64, 64), (2, 12, 3, 16, 16),
+                                      (2, 8, 4, 9, 7), (1, 32, 8, 96, 40)])
+def test_groupnorm_swish_vs_torch(B, C, G, H, W):
+    """GroupNorm(eps 1e-6) + swish through groupnorm_coef / affine_act vs torch's float64 group_norm: the
+    register-resident single-read kernels (planes up to 256x256, 256- and 1024-thread forms) and the generic two-sweep
+    fallback (odd sizes)"""
+    from inverseproblemwithdiffusionmodel_amd import ops
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(B, C, H, W, generator=gen) * 3.0 + 5.0 * torch.randn(B, C, 1, 1, generator=gen)
+    w, b = torch.randn(C, generator=gen), torch.randn(C, generator=gen)
+    want = torch.nn.functional.silu(torch.nn.functional.group_norm(x.double(), G, w.double(), b.double(), eps=1e-6))
+    coef = ops.groupnorm_coef(x.cuda(), w.cuda(), b.cuda(), G, eps=1e-6)
+    got = ops.affine_act(x.cuda(), coef, ops.ACT_SWISH).cpu().double()
+    assert (got - want).abs().max() < 2e-5 * max(1.0, float(want.abs().max()))
