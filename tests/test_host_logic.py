@@ -166,3 +166,28 @@ def test_metrics_and_checkpoint_ingestion(tmp_path):
     load_model.load_scorenet_weights(dst, path)
     for k, v in src.state_dict().items():
         assert torch.equal(dst.state_dict()[k], v)
+
+
+def test_conv_dispatch_host_rules():
+    """host-side decision functions of the C ABI (no GPU needed): blob sizes, Winograd eligibility, split-K choice"""
+    from inverseproblemwithdiffusionmodel_amd import _lib, ops
+    L = _lib.lib
+    # three bf16 pieces per weight, padded to 16 input / 32 output channels
+    assert L.ipdm_conv_bx3_weight_bytes(128, 128, 3) == 9 * 8 * 4 * 3072
+    assert L.ipdm_conv_bx3_weight_bytes(1, 1, 3) == 9 * 3072 and L.ipdm_conv_bx3_weight_bytes(64, 64, 27) == 27 * 4 * 2 * 3072
+    assert L.ipdm_conv_bx3_weight_bytes(64, 64, 5) == -1
+    assert L.ipdm_conv_wino_bx3_weight_bytes(256, 128) == 16 * 8 * 8 * 3072
+    # Winograd: 3x3, Cin % 16, Cout % 64, even sizes; small / dilated images need H, W % (2 dil)
+    assert L.ipdm_conv2d_wino_bx3_supported(128, 128, 128, 128, 1) == 1
+    assert L.ipdm_conv2d_wino_bx3_supported(120, 128, 128, 128, 1) == 0 and L.ipdm_conv2d_wino_bx3_supported(128, 96, 64, 64, 1) == 0
+    assert L.ipdm_conv2d_wino_bx3_supported(512, 512, 16, 16, 4) == 1 and L.ipdm_conv2d_wino_bx3_supported(512, 512, 18, 16, 4) == 0
+    assert L.ipdm_conv2d_wino_bx3_supported(64, 64, 31, 32, 1) == 0
+    # dispatch rule of the modules: 16-pixel undilated images only with enough (image, channel tile) pairs
+    assert ops.wino_bx3_pays(512, 512, 16, 16, 1, B=28) and not ops.wino_bx3_pays(256, 256, 16, 16, 1, B=28)
+    assert ops.wino_bx3_pays(128, 128, 128, 128, 1, B=28) and ops.wino_bx3_pays(512, 512, 16, 16, 2, B=28)
+    assert not ops.wino_bx3_pays(384, 128, 256, 256, 1, B=16)            # beyond the buffer-descriptor reach
+    # split-K: only 16-pixel configurations, either 1 or the number of 8-chunk groups, chosen by the tile count
+    sk = L.ipdm_conv_bx3_splitk
+    assert sk(28, 1, 256, 256, 16, 16, 3, 1) == 2 and sk(26, 1, 256, 256, 16, 16, 3, 1) == 2     # both shard sizes split alike
+    assert sk(210, 1, 256, 256, 16, 16, 3, 1) == 1 and sk(1, 1, 512, 512, 4, 4, 3, 1) == 4
+    assert sk(1, 1, 128, 128, 16, 16, 3, 1) == 1 and sk(28, 1, 256, 256, 32, 32, 3, 1) == 1       # one group / wide image
