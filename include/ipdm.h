@@ -251,6 +251,12 @@ int ipdm_conv_bx3_splitk_f32(const float* x, const void* packed, const float* bi
                              int B, int Cin, int Cout, int D, int H, int W, int k, int dilation, int volume, int ksplit,
                              float* work, void* stream);
 
+/* One torch.optim.Adam step (no weight decay / amsgrad) in place on x along the ASCENT direction g, i.e. with
+ * param.grad = -g as the reference's MAP optimizers hand it over (ncsn/models/MAP_optimizers.py:72-74,103-105);
+ * m, v: first / second moment buffers (zero-initialised by the caller), step = 1, 2, ... */
+int ipdm_adam_ascent_f32(float* x, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                         float eps, int step, void* stream);
+
 /* Winograd F(2x2,3x3) with split-bf16 operands (3x3, Cin % 16 == 0, Cout % 64 == 0, see ..._supported): the same
  * call sites and output options as ipdm_conv2d_wino_f32; weights transformed, split and laid out once per layer into
  * a blob of ipdm_conv_wino_bx3_weight_bytes(Cout, Cin) bytes. */

@@ -64,6 +64,7 @@ SIGNATURES = {
     "ipdm_conv3d_bx3_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 8 + [P],
     "ipdm_conv_bx3_splitk": [c_int] * 8,
     "ipdm_conv_bx3_splitk_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 10 + [P, P],
+    "ipdm_adam_ascent_f32": [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_int, P],
     "ipdm_conv_wino_bx3_weight_bytes": [c_int, c_int],
     "ipdm_conv_wino_bx3_pack_weight": [P, P, c_int, c_int, P],
     "ipdm_conv2d_wino_bx3_supported": [c_int, c_int, c_int, c_int, c_int],

@@ -223,7 +223,35 @@ __global__ __launch_bounds__(256) void sample_norm_kernel(const float* __restric
   if (threadIdx.x == 0) norms[blockIdx.x] = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
 }
 
+// torch.optim.Adam (no weight decay, no amsgrad), one step in place on x with the ASCENT direction g (the reference
+// hands Adam param.grad = -grad, MAP_optimizers.py:103-104):  m = b1 m + (1-b1)(-g);  v = b2 v + (1-b2) g^2;
+// x -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_ascent_kernel(float* __restrict__ x, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                          float b1, float b2, float step_size, float sqrt_bc2,
+                                                          float eps) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gr = -g[i];
+    const float mi = m[i] + (gr - m[i]) * (1.f - b1);        // lerp, as torch
+    const float vi = v[i] * b2 + (1.f - b2) * (gr * gr);
+    m[i] = mi;
+    v[i] = vi;
+    x[i] = x[i] - step_size * (mi / (sqrtf(vi) / sqrt_bc2 + eps));
+  }
+}
+
 }  // namespace
+
+extern "C" int ipdm_adam_ascent_f32(float* x, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                    float beta2, float eps, int step, void* stream) {
+  IPDM_REQUIRE(n >= 0 && step >= 1 && lr > 0.f);
+  if (n == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && g && m && v);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_ascent_kernel, dim3(ipdm_ew_grid(n, 256)), dim3(256), 0, ipdm_stream(stream), x, g, m, v,
+                     (long long)n, beta1, beta2, (float)((double)lr / bc1), (float)sqrt(bc2), eps);
+  return ipdm_launch_status();
+}
 
 extern "C" int ipdm_groupnorm_coef_f32(const float* x, const float* weight, const float* bias, float* coef, int B, int C,
                                        int HW, int G, float eps, void* stream) {

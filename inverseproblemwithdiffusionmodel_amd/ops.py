@@ -563,3 +563,11 @@ def wino_bx3_pays(Cin, Cout, H, W, dilation=1, B=1):
     if B * Cin * H * W * 4 >= (0x1fffffff if (W < 32 or dilation > 1) else 0x3fffffff):   # buffer-descriptor reach
         return False
     return conv_wino_bx3_supported(Cin, Cout, H, W, dilation)
+
+
+def adam_ascent(x, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8):
+    """one torch.optim.Adam step in place on x with param.grad = -g (x, g, m, v: same-shaped float32 GPU tensors)"""
+    x = _gpu(x, torch.float32, "x")
+    call("ipdm_adam_ascent_f32", _ptr(x), _ptr(g), _ptr(m), _ptr(v), x.numel(), float(lr), float(betas[0]), float(betas[1]),
+         float(eps), int(step), _stream())
+    return x

@@ -409,6 +409,36 @@ def g08_ald(net, cfg):
     save("g08_ald", **out)
 
 
+def g18_map(net, cfg):
+    """MAP baseline: the reference's SENSEMAP (= MAPOptimizer, MAP_optimizers.py:55-116) on the
+    tiny score net: 50 Adam(0.5, 0.5) iterations on x from the zero-filled reconstruction"""
+    from InverseProblemWithDiffusionModel.ncsn.models import MAP_optimizers as ref_map
+    H = W = 32
+    orig = ref_uf.RandomUndersamplingFourier._generate_mask
+    try:
+        ref_uf.RandomUndersamplingFourier._generate_mask = t1_mask_patch(MASK_PARAMS["R8"])
+        with quiet:
+            op = ref_uf.SENSE("exp", 4, 8, 0.04, (1, H, W), seed=0)
+    finally:
+        ref_uf.RandomUndersamplingFourier._generate_mask = orig
+    g = torch.Generator().manual_seed(18)
+    img = torch.complex(torch.rand(1, 1, H, W, generator=g), 0.3 * torch.randn(1, 1, H, W, generator=g))
+    meas = op(img)
+    out = {"img": npy(img), "measurement": npy(meas)}
+    for tag, lamda, lr in [("a", 1e-2, 1e-3), ("b", 0.5, 5e-3)]:
+        cfg_map = Namespace(**vars(cfg))
+        cfg_map.MAP = Namespace(n_iters=50, lr=lr, complex_inner_n_steps=20)
+        x_init = op.conj_op(meas).clone()
+        out[f"{tag}_x_init"] = npy(x_init).copy()
+        opt = ref_map.SENSEMAP(x_init, meas, net, op, lamda, cfg_map, logger=MagicMock(), device=torch.device("cpu"))
+        with quiet, contextlib.redirect_stderr(io.StringIO()):
+            x = opt()
+        torch.set_grad_enabled(True)
+        out[f"{tag}_lamda"], out[f"{tag}_lr"] = np.array(lamda), np.array(lr)
+        out[f"{tag}_x"] = npy(x)
+    save("g18_map", **out)
+
+
 def g09_upfirdn():
     out = {}
     g = torch.Generator().manual_seed(9)
@@ -669,6 +699,11 @@ if __name__ == "__main__":
         net, cfg = g07_layers()
         g08_ald(net, cfg)
         g12_g16_g17_2dtime(net, cfg)
+    if which is not None and "g18" in which and not ("g07" in which or "g08" in which or "g17" in which):
+        net, cfg = g07_layers()
+        g18_map(net, cfg)
+    elif which is None or "g18" in which:
+        g18_map(net, cfg)
     if which is None or "g13" in which or "g14" in which:
         g13_g14_score_sde()
     if which is None or "g15" in which:

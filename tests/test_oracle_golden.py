@@ -248,3 +248,26 @@ def test_metrics_definitions():
     assert metrics.ssim(a, a) == pytest.approx(1.0)
     assert metrics.nrmse(a, a) == 0.0
     assert metrics.nrmse(a, b) == pytest.approx(np.linalg.norm(a - b) / np.linalg.norm(a))
+
+
+# ---- G18: MAP baseline (SENSEMAP = MAPOptimizer with Adam(0.5, 0.5)) ---------------------------------------------
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_map_sense_golden(golden, tag):
+    from oracle import map as omap
+    g = golden("g18_map")
+    maps = kspace.sens_maps(4, 32, 32, 0)
+    mask = kspace.generate_mask(1, 32, seed=0, **kspace.MASK_PARAMS["R8"])[None]
+    score = _tiny_score(golden)
+
+    def score_np(x, labels):
+        with torch.no_grad():
+            return score(torch.from_numpy(x), torch.from_numpy(labels)).numpy()
+
+    x = omap.sense_map(g[f"{tag}_x_init"], g["measurement"], score_np, lambda v: kspace.sense_forward(v, maps, mask),
+                       lambda s: kspace.sense_adjoint(s, maps), float(g[f"{tag}_lamda"]), float(g[f"{tag}_lr"]), 50)
+    ref = g[f"{tag}_x"]
+    assert np.abs(ref - g[f"{tag}_x_init"]).max() > 0.05          # the optimiser moved the image
+    # Adam's m / sqrt(v) turns rounding-level gradient differences into O(lr) steps where the gradient is ~0:
+    # a handful of pixels differ by up to 1 % of the distance travelled (50 * lr); the image metric is the gate
+    np.testing.assert_allclose(x, ref, atol=0.02 * 50 * float(g[f"{tag}_lr"]))
+    assert metrics.nrmse(np.abs(x), np.abs(ref)) < 1e-3

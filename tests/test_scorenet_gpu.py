@@ -227,3 +227,22 @@ def test_full_size_trajectory_bf16x3_vs_fp32_mfma():
         assert metrics.nrmse(ma, mb) < 1e-5
         assert abs(metrics.ssim(ma[0], mb[0]) - 1.0) < 1e-5
     assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max()
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_map_sense_golden_gpu(pkg, tiny_net, golden, tag):
+    """MAP baseline SENSEMAP (50 Adam iterations) on the GPU kernels vs the reference's own run"""
+    from inverseproblemwithdiffusionmodel_amd.ncsn.models.MAP_optimizers import SENSEMAP
+    from inverseproblemwithdiffusionmodel_amd.ncsn.linear_transforms.undersampling_fourier import SENSE
+    g = golden("g18_map")
+    op = SENSE("exp", 4, 8, 0.04, (1, 32, 32), seed=0)
+    cfg = tiny_config()
+    cfg.MAP = Namespace(n_iters=50, lr=float(g[f"{tag}_lr"]), complex_inner_n_steps=20)
+    x_init = torch.from_numpy(g[f"{tag}_x_init"].copy()).cuda()
+    opt = SENSEMAP(x_init, torch.from_numpy(g["measurement"]).cuda(), tiny_net, op, float(g[f"{tag}_lamda"]), cfg,
+                   logger=None, device=torch.device("cuda"))
+    x = opt().cpu().numpy()
+    ref = g[f"{tag}_x"]
+    np.testing.assert_allclose(x, ref, atol=0.02 * 50 * float(g[f"{tag}_lr"]))      # see test_oracle_golden.py
+    assert metrics.nrmse(np.abs(x), np.abs(ref)) < 1e-3
+    assert np.array_equal(x_init.cpu().numpy(), x)                # updated in place, as the reference's parameter
