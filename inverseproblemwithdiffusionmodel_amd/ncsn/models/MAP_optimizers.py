@@ -10,8 +10,8 @@ with unit coefficient (z - A^H(A z - y)) minus z, the two score evaluations are 
 
 Differences: only the default optimiser (Adam, optionally with other betas / eps through ``opt_params``) is built --
 ``opt_class`` must be None or torch.optim.Adam; ``logger`` may be None (scalars are logged when given, the image panel
-every n_iters // 50 iterations as the reference); ``UndersamplingFourier`` (magnitude-only variant) and
-``MAPOptimizer2DTime`` are not built."""
+every n_iters // 50 iterations as the reference); ``UndersamplingFourier`` (magnitude-only variant) is not built;
+``MAPOptimizer2DTime`` (below) logs only the gradient norm and writes no GIF / screenshot panels."""
 import torch
 
 from ... import ops
@@ -79,3 +79,88 @@ class Inpainting(MAPOptimizer):
 
 class SENSEMAP(MAPOptimizer):
     pass
+
+
+class MAPOptimizer2DTime(object):
+    """2D+time MAP baseline (reference :154-365): x (B, T, C, H, W) complex; per iteration
+        grad = data + prior_weight * (spatial_step_weight * grad_S + temporal_step_weight * grad_T)
+    and one Adam step on the real and on the imaginary part (the reference's two optimisers evaluate the same gradient
+    from the same x, so they are one elementwise Adam on the planar state).  ``params`` keys as the reference: lr,
+    opt_class (None / torch.optim.Adam), opt_params, device, num_iters, num_plot_times, win_size, prior_weight,
+    spatial_step_weight, temporal_step_weight, save_dir, mode_T in [diffusion1d, tv], if_random_shift."""
+
+    def __init__(self, x_init, measurement, scorenet_S, scorenet_T, linear_tfm, logger, params):
+        import numpy as np
+        self.params = params
+        oc = params.get("opt_class")
+        if oc is not None and oc is not torch.optim.Adam:
+            raise NotImplementedError("only torch.optim.Adam semantics are built (ipdm_adam_ascent_f32)")
+        op = dict(params.get("opt_params", {}))
+        if set(op) - {"betas", "eps"}:
+            raise NotImplementedError(f"Adam options {sorted(set(op) - {'betas', 'eps'})} are not built")
+        self.betas, self.eps = tuple(op.get("betas", (0.9, 0.999))), op.get("eps", 1e-8)
+        self.x = x_init
+        self.measurement = measurement
+        self.scorenet_S, self.scorenet_T = scorenet_S, scorenet_T
+        self.win_size = int(np.sqrt(self.scorenet_T.config.data.channels))
+        self.linear_tfm = linear_tfm
+        self.device = params.get("device") or torch.device("cuda")
+        self.logger = logger
+        self.finite_diff = None
+
+    def temporal_grad(self, x, mode_T, if_random_shift):
+        """x (B, T, C, H, W) complex64 on the device -> temporal prior gradient, same shape"""
+        import numpy as np
+        from ..linear_transforms.finite_diff import FiniteDiff
+        from ...helpers.utils import reshape_temporal_dim
+        if mode_T == "tv":
+            if self.finite_diff is None:
+                self.finite_diff = FiniteDiff(dims=1)
+            return torch.complex(self.finite_diff.log_lh_grad(x.real), self.finite_diff.log_lh_grad(x.imag))
+        if mode_T != "diffusion1d":
+            raise ValueError(f"mode_T {mode_T!r}: expected 'diffusion1d' or 'tv'")
+        B, T, C, H, W = x.shape
+        win = self.params["win_size"]
+        v = x.permute(0, 2, 1, 3, 4).reshape(B * C, T, H, W)
+        if if_random_shift:
+            shifts_np = np.random.randint(0, self.win_size, (2,))             # host RNG, one shift per iteration (:309)
+            v = torch.roll(v, shifts=tuple(shifts_np.tolist()), dims=(-2, -1))
+        p = reshape_temporal_dim(v, win, win, "forward")                      # (B', kx*ky, T)
+        n = p.shape[0]
+        labels = torch.ones(2 * n, dtype=torch.long, device=x.device)
+        s = self.scorenet_T(torch.cat([p.real, p.imag], dim=0).contiguous().float(), labels)
+        gT = reshape_temporal_dim(torch.complex(s[:n], s[n:]), win, win, "backward", img_size=(H, W))
+        if if_random_shift:
+            gT = torch.roll(gT, shifts=tuple((-shifts_np).tolist()), dims=(-2, -1))
+        return gT.reshape(B, C, T, H, W).permute(0, 2, 1, 3, 4)
+
+    @torch.no_grad()
+    def __call__(self):
+        P, dev, tfm = self.params, self.device, self.linear_tfm
+        x0 = self.x.to(dev).to(torch.complex64)
+        B, T, C, H, W = x0.shape
+        N = B * T * C
+        xs = torch.cat([x0.real.reshape(N, 1, H, W), x0.imag.reshape(N, 1, H, W)], dim=0).contiguous().float()
+        y = self.measurement.to(dev).to(torch.complex64).reshape(self.measurement.shape[0], N, 1, H, W).contiguous()
+        sens, mask = tfm.sens_f32(dev), tfm.mask_u8(dev)
+        m, v = torch.zeros_like(xs), torch.zeros_like(xs)
+        px = torch.empty_like(xs)
+        work = torch.empty(N * H * W * 2, dtype=torch.float32, device=dev)
+        labels = torch.ones(2 * N, dtype=torch.long, device=dev)
+        pw, wS, wT = P["prior_weight"], P["spatial_step_weight"], P["temporal_step_weight"]
+        for it in range(P["num_iters"]):
+            ops.sense_l2prox(xs[:N], xs[N:], y, sens, mask, 1.0, out_re=px[:N], out_im=px[N:], work=work)
+            grad = ops.axpby(px, xs, 1.0, -1.0)                                        # data term: -A^H(A x - y)
+            grad = ops.axpby(grad, self.scorenet_S(xs, labels), 1.0, float(pw * wS))   # + spatial prior
+            xc = torch.complex(xs[:N], xs[N:]).reshape(B, T, C, H, W)
+            gT = self.temporal_grad(xc, P["mode_T"], P.get("if_random_shift", False))
+            gTp = torch.cat([gT.real.reshape(N, 1, H, W), gT.imag.reshape(N, 1, H, W)], dim=0).contiguous().float()
+            grad = ops.axpby(grad, gTp, 1.0, float(pw * wT))                           # + temporal prior
+            ops.adam_ascent(xs, grad, m, v, P["lr"], it + 1, betas=self.betas, eps=self.eps)
+            if self.logger is not None:
+                self.logger.add_scalar("grad", float(torch.linalg.vector_norm(grad)), global_step=it)
+        self.x = torch.complex(xs[:N], xs[N:]).reshape(B, T, C, H, W)
+        return self.get_reconstruction()
+
+    def get_reconstruction(self):
+        return self.x.detach().cpu()

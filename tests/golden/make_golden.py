@@ -665,6 +665,30 @@ def g12_g16_g17_2dtime(net2d, cfg2d):
         out[f"{mode}_noise_sum"] = np.array(float(sum(float(n.astype(np.float64).sum()) for n in tape.tape)))
     save("g17_ald2dtime", **out)
 
+    # g19: the 2D+time MAP baseline (MAPOptimizer2DTime, MAP_optimizers.py:154-365): 12 Adam iterations, both temporal modes
+    ref_map = importlib.import_module("InverseProblemWithDiffusionModel.ncsn.models.MAP_optimizers")
+    ref_map.save_vol_as_gif = lambda *a, **k: None
+    ref_map.vis_images = lambda *a, **k: None
+    ref_map.vis_multi_channel_signal = lambda *a, **k: None
+    out = {"measurement": npy(meas)}
+    for mode in ["diffusion1d", "tv"]:
+        with quiet:
+            netT3 = ref_ncsn3d.NCSN3DShallow(cfgT).eval()
+        netT3.load_state_dict(netT.state_dict())
+        x_init = op.conj_op(meas.reshape(4, B * T, 1, H, W)).reshape(B, T, 1, H, W).clone()
+        out[f"{mode}_x_init"] = npy(x_init).copy()
+        mp = dict(lr=2e-3, opt_class=torch.optim.Adam, opt_params={"betas": (0.5, 0.5)}, device=torch.device("cpu"),
+                  num_iters=12, num_plot_times=1000, win_size=8, prior_weight=0.3, spatial_step_weight=1.0,
+                  temporal_step_weight=0.5, save_dir="/tmp/ipdm_oracle/out", mode_T=mode, if_random_shift=False)
+        mp["num_plot_times"] = 12                                   # plot_interval = 1
+        opt = ref_map.MAPOptimizer2DTime(x_init, meas, net2d, netT3, op, MagicMock(), mp)
+        with quiet, contextlib.redirect_stderr(io.StringIO()):
+            res = opt()
+        torch.set_grad_enabled(True)
+        out[f"{mode}_x"] = npy(res)
+    out["params"] = np.array([2e-3, 0.3, 1.0, 0.5, 12])               # lr, prior, spatial, temporal weights, iterations
+    save("g19_map2dtime", **out)
+
 
 def g15_fullnet():
     """Full-size ACDC score net on the synthetic weights the benchmark uses."""
