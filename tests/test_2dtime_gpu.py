@@ -138,6 +138,9 @@ def test_map2dtime_golden(golden, net3d, mode):
     from inverseproblemwithdiffusionmodel_amd.ncsn.models.MAP_optimizers import MAPOptimizer2DTime
     from inverseproblemwithdiffusionmodel_amd.ncsn.linear_transforms.undersampling_fourier import SENSE
     g7, g = golden("g07_layers"), golden("g19_map2dtime")
+    # ALD2DTime.__init__ REPLACES scorenet_T.sigmas by its aligned schedule (as the reference does, :345-346); the MAP
+    # optimiser takes the network as loaded, so give the shared fixture its own noise levels back
+    net3d.sigmas = torch.from_numpy(golden("g16_ncsn3d")["net3d__sigmas"]).cuda()
     net2d = ncsnv2.NCSNv2Deepest(tiny_config())
     net2d.load_state_dict(state_dict_from_golden(g7, "net"), strict=True)
     net2d = net2d.cuda().eval()
