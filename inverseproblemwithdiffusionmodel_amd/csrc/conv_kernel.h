@@ -425,7 +425,5 @@ int conv_wino_weights(const float* w, float* U, int Cout, int Cin, hipStream_t s
 bool wino_bx3_ok(const ConvArgs& a, int ks);
 int conv_wino_bx3_launch(ConvArgs a, hipStream_t s);
 int conv_wino_bx3_weights(const float* w, void* U, int Cout, int Cin, hipStream_t s);
-// wave-specialised form (conv_wino_bx3_spec.hip): multiplier / stager waves, 64 channels x 32 tiles per workgroup
-int conv_wino_bx3_spec_launch(ConvArgs a, bool small_dma, int cus_per_xcd, hipStream_t s);
 
 }  // namespace ipdm_conv

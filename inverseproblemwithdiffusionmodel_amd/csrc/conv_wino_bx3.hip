@@ -39,23 +39,6 @@ constexpr int X_RCH = 384;                                       // floats per c
 constexpr int X_R_ELEMS = 27 * 256;                              // >= 16 x 384 (dword form) and 27 quad pieces (DMA4, 8x8 tiles)
 constexpr size_t X_LDS_BYTES = (2 * (size_t)X_V_ELEMS + X_R_ELEMS) * sizeof(float);   // 128 KiB + 24 KiB
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// two fp32 -> one dword of two bf16 (round to nearest even): v_cvt_pk_bf16_f32
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  const f32x2 v = {lo, hi};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-
-#ifndef X_PROBE
-#define X_PROBE 0                        // diagnostic builds: compile pieces of the hand-placed steps out
-#endif
-#ifndef IPDM_WBX3_HAND
-#define IPDM_WBX3_HAND 1                 // 16-byte-DMA persistent kernel: hand-placed MFMA gaps (0 = compiler-scheduled steps)
-#endif
-
 // U[p = a*4+b][co][ci] = sum_ij G[a][i] g[co][ci][i][j] G[b][j], split into three bf16 pieces, stored as MFMA
 // A fragments: [p][cc = ci/16][ct = co/32][piece][h][r][8]  (lane (r, h) holds ci = 16cc + 8h .. +7 of co = 32ct + r)
 __global__ __launch_bounds__(256) void wino_bx3_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
@@ -626,159 +609,6 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   // ---- prologue of the first tile ----
   Geo cur_g = geo_of(tile);
   bf16x8 afr[2][2][3];
-
-  // ---- hand-placed steps (DMA4 form).  hipcc honours sched_group_barrier only partly here: it leaves runs of a dozen
-  // back-to-back MFMAs followed by a clump of 40-120 VALU / LDS instructions, and the partner wave of the SIMD is in the
-  // same phase.  So every piece of per-chunk work is cut into slices of <= ~10 instructions, each slice is written
-  // behind the MFMA whose gap it goes into, and a sched_barrier(0) fences the gap.
-  //   B operand: packed bf16 pairs bq[buffer][piece][pair]; the split of the NEXT step's 8 values = slices a/b x 4 pairs
-  //   transform of a patch: read (8 LDS) -> 4 x dpp row -> 4 x column pass -> 4 x (row pass + 4 V stores)
-  u32x4 bq[2][3];
-  float raw8[8], res0[4], res1[4];
-  float2 pq[4];
-  float pe[4], tmpx[16];
-  auto load_raw = [&](const float* cur, int pi, int tg) {
-    const float* bp = cur + (p0 + pi) * (X_KC * X_TILES) + tg * 32 + b_lane;
-#pragma unroll
-    for (int qq = 0; qq < 8; ++qq) raw8[qq] = bp[qq * X_TILES];
-  };
-  auto slice_a = [&](auto bc, auto qc) {                      // h and m pieces of pair q
-    constexpr int nb = decltype(bc)::value, qv = decltype(qc)::value;
-    const float x0 = raw8[2 * qv], x1 = raw8[2 * qv + 1];
-    const unsigned hp = cvt_pk_bf16(x0, x1);
-    res0[qv] = x0 - __builtin_bit_cast(float, hp << 16);
-    res1[qv] = x1 - __builtin_bit_cast(float, hp & 0xffff0000u);
-    bq[nb][0][qv] = hp;
-    bq[nb][1][qv] = cvt_pk_bf16(res0[qv], res1[qv]);
-  };
-  auto slice_b = [&](auto bc, auto qc) {                      // l piece of pair q
-    constexpr int nb = decltype(bc)::value, qv = decltype(qc)::value;
-    const unsigned mp = bq[nb][1][qv];
-    const float s0 = res0[qv] - __builtin_bit_cast(float, mp << 16);
-    const float s1 = res1[qv] - __builtin_bit_cast(float, mp & 0xffff0000u);
-    bq[nb][2][qv] = cvt_pk_bf16(s0, s1);
-  };
-  const int txl_h = mytile % TX;
-  const bool first_h = txl_h == 0, last_h = txl_h == TX - 1;
-  auto p_read = [&](int kc) {
-    if constexpr (DMA4) {
-      const float* rp = rs + kc * (QN * 4) + r_lane;
-      const int edge = first_h ? 1 : 4;
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        pq[rr] = *reinterpret_cast<const float2*>(rp + rr * RC4 + 2);
-        pe[rr] = rp[rr * RC4 + edge];
-      }
-    }
-  };
-  auto p_dpp = [&](auto rc) {
-    constexpr int rr = decltype(rc)::value;
-    const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, pq[rr].y), 0x111, 0xf, 0xf, false));
-    const float right = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, pq[rr].x), 0x101, 0xf, 0xf, false));
-    dreg[rr * 4 + 0] = first_h ? pe[rr] : left;
-    dreg[rr * 4 + 1] = pq[rr].x;
-    dreg[rr * 4 + 2] = pq[rr].y;
-    dreg[rr * 4 + 3] = last_h ? pe[rr] : right;
-  };
-  auto p_col = [&](auto cc) {
-    constexpr int c = decltype(cc)::value;
-    tmpx[0 * 4 + c] = dreg[0 * 4 + c] - dreg[2 * 4 + c];
-    tmpx[1 * 4 + c] = dreg[1 * 4 + c] + dreg[2 * 4 + c];
-    tmpx[2 * 4 + c] = dreg[2 * 4 + c] - dreg[1 * 4 + c];
-    tmpx[3 * 4 + c] = dreg[1 * 4 + c] - dreg[3 * 4 + c];
-  };
-  auto p_row = [&](auto rc, float* st, int kc) {
-    constexpr int rr = decltype(rc)::value;
-    float* vs = st + kc * X_TILES + mytile;
-    vs[(rr * 4 + 0) * X_KC * X_TILES] = tmpx[rr * 4 + 0] - tmpx[rr * 4 + 2];
-    vs[(rr * 4 + 1) * X_KC * X_TILES] = tmpx[rr * 4 + 1] + tmpx[rr * 4 + 2];
-    vs[(rr * 4 + 2) * X_KC * X_TILES] = tmpx[rr * 4 + 2] - tmpx[rr * 4 + 1];
-    vs[(rr * 4 + 3) * X_KC * X_TILES] = tmpx[rr * 4 + 1] - tmpx[rr * 4 + 3];
-  };
-  auto dma_piece = [&](auto kc_, int chunk) {
-    constexpr int k = decltype(kc_)::value;
-    if constexpr (DMA4) {
-      static_assert(!DMA4 || NI >= 24, "pieces 0-2 of every wave exist");
-      const int soff = (int)(((size_t)dma_b * a.Cin + chunk * X_KC) * HW * 4);
-      if (k < 3 || wave + 8 * k < NI) {                       // k = 3: wave-uniform branch, issued outside the fenced gaps
-#if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(rs + (wave + 8 * k) * 256),
-                                                 16, dma_off[k], soff, 0, 0);
-#endif
-      }
-    }
-  };
-  // one step = 12 MFMAs of (position pi, tile group tg), the two channel tiles' chains interleaved
-  auto hstep = [&](auto sc, const float* cur, float* nxt, int ch, int a_chunk, int a_cot, int dma_chunk) {
-    constexpr int st = decltype(sc)::value;
-    constexpr int pi = st >> 1, tg = st & 1, cb = st & 1;
-    using NB = std::integral_constant<int, ((st + 1) % 2)>;
-    if constexpr (st < 3) load_raw(cur, (st + 1) >> 1, (st + 1) & 1);
-    if constexpr (st == 0 && !(X_PROBE & 1)) p_read(2 * wave);
-    if constexpr (st == 1 && !(X_PROBE & 2)) dma_piece(std::integral_constant<int, 3>{}, dma_chunk);
-    const uint4* ap = nullptr;                                // st 0: position p0+1 of this chunk; st 2: p0 of the next
-    if constexpr (st == 0) ap = wq + (size_t)(p0 + 1) * pos_stride + ((size_t)ch * n_ct + cur_g.co_tile * 2) * 192 + lane;
-    if constexpr (st == 2) ap = wq + (size_t)p0 * pos_stride + ((size_t)a_chunk * n_ct + a_cot * 2) * 192 + lane;
-    const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[cb][0]), bm = __builtin_bit_cast(bf16x8, bq[cb][1]),
-                 bl = __builtin_bit_cast(bf16x8, bq[cb][2]);
-    f32x16 v0 = acc[pi][0][tg], v1 = acc[pi][1][tg];
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<12>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      constexpr int c = i & 1, k = i >> 1;
-      constexpr int ai = k == 0 ? 2 : (k == 2 || k == 3) ? 1 : 0;                 // A piece: l h m m h h
-      const bf16x8 bb = (k == 0 || k == 3 || k == 5) ? bh : (k == 1 ? bl : bm);   // B piece: h l m h m h
-      if constexpr (c == 0)
-        v0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][0][ai], bb, v0, 0, 0, 0);
-      else
-        v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][1][ai], bb, v1, 0, 0, 0);
-      if constexpr ((st == 0 || st == 2) && i < 2 && !(X_PROBE & 4)) {
-#pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) afr[st == 0 ? 1 : 0][i][s3] = __builtin_bit_cast(bf16x8, ap[i * 192 + s3 * 64]);
-      }
-      if constexpr (st < 3 && i >= 2 && i < 10 && !(X_PROBE & 8)) {
-        using Q = std::integral_constant<int, ((i - 2) / 2)>;
-        if constexpr ((i & 1) == 0) slice_a(NB{}, Q{}); else slice_b(NB{}, Q{});
-      }
-      if constexpr (st == 0 && !(X_PROBE & 1)) {
-        if constexpr (i >= 2 && i < 6) p_dpp(std::integral_constant<int, (i >= 2 && i < 6) ? i - 2 : 0>{});
-        if constexpr (i == 6) {
-          p_col(std::integral_constant<int, 0>{});
-          p_col(std::integral_constant<int, 1>{});
-        }
-        if constexpr (i == 7) {
-          p_col(std::integral_constant<int, 2>{});
-          p_col(std::integral_constant<int, 3>{});
-          p_read(2 * wave + 1);
-        }
-        if constexpr (i >= 8) p_row(std::integral_constant<int, (i >= 8) ? i - 8 : 0>{}, nxt, 2 * wave);
-        if constexpr (i == 10) {
-          p_dpp(std::integral_constant<int, 0>{});
-          p_dpp(std::integral_constant<int, 1>{});
-        }
-        if constexpr (i == 11) {
-          p_dpp(std::integral_constant<int, 2>{});
-          p_dpp(std::integral_constant<int, 3>{});
-        }
-      }
-      if constexpr (st == 1) {
-        if constexpr (i < 3 && !(X_PROBE & 2)) dma_piece(std::integral_constant<int, (i < 3) ? i : 0>{}, dma_chunk);
-        if constexpr (i == 2 && !(X_PROBE & 1)) {
-          p_col(std::integral_constant<int, 0>{});
-          p_col(std::integral_constant<int, 1>{});
-        }
-        if constexpr (i == 3 && !(X_PROBE & 1)) {
-          p_col(std::integral_constant<int, 2>{});
-          p_col(std::integral_constant<int, 3>{});
-        }
-        if constexpr (i >= 4 && i < 8 && !(X_PROBE & 1)) p_row(std::integral_constant<int, (i >= 4 && i < 8) ? i - 4 : 0>{}, nxt, 2 * wave + 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    acc[pi][0][tg] = v0;
-    acc[pi][1][tg] = v1;
-  };
-
   load_A(afr[0], p0, 0, cur_g.co_tile);
   set_dma_geo(cur_g);
   issue_dma(0);
@@ -809,18 +639,6 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       const bool a_next = ch + 1 >= n_chunks;
       const int a_chunk = a_next ? 0 : ch + 1;
       const int a_cot = a_next ? next_g.co_tile : cur_g.co_tile;
-      if constexpr (DMA4 && IPDM_WBX3_HAND) {
-        load_raw(cur, 0, 0);
-        static_for<4>([&](auto qc) {
-          slice_a(std::integral_constant<int, 0>{}, qc);
-          slice_b(std::integral_constant<int, 0>{}, qc);
-        });
-        hstep(std::integral_constant<int, 0>{}, cur, nxt, ch, a_chunk, a_cot, dma_chunk);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone has read the raw stage
-        hstep(std::integral_constant<int, 1>{}, cur, nxt, ch, a_chunk, a_cot, dma_chunk);
-        hstep(std::integral_constant<int, 2>{}, cur, nxt, ch, a_chunk, a_cot, dma_chunk);
-        hstep(std::integral_constant<int, 3>{}, cur, nxt, ch, a_chunk, a_cot, dma_chunk);
-      } else {
       bf16x8 bs[2][3];
       float raw[8];
       load_B(raw, cur, 0, 0);
@@ -841,25 +659,6 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
         if constexpr (st == 2) load_A(afr[0], p0, a_chunk, a_cot);
         if constexpr (st < 3) split3(raw, bs[(st + 1) & 1][0], bs[(st + 1) & 1][1], bs[(st + 1) & 1][2]);
         const bf16x8 bh = bs[st & 1][0], bm = bs[st & 1][1], bl = bs[st & 1][2];
-#ifdef IPDM_WBX3_ILV
-        {
-          f32x16 v0 = acc[pi][0][tg], v1 = acc[pi][1][tg];
-          v0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][0][2], bh, v0, 0, 0, 0);
-          v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][1][2], bh, v1, 0, 0, 0);
-          v0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][0][0], bl, v0, 0, 0, 0);
-          v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][1][0], bl, v1, 0, 0, 0);
-          v0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][0][1], bm, v0, 0, 0, 0);
-          v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][1][1], bm, v1, 0, 0, 0);
-          v0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][0][1], bh, v0, 0, 0, 0);
-          v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][1][1], bh, v1, 0, 0, 0);
-          v0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][0][0], bm, v0, 0, 0, 0);
-          v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][1][0], bm, v1, 0, 0, 0);
-          v0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][0][0], bh, v0, 0, 0, 0);
-          v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][1][0], bh, v1, 0, 0, 0);
-          acc[pi][0][tg] = v0;
-          acc[pi][1][tg] = v1;
-        }
-#else
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           f32x16 v = acc[pi][c][tg];
@@ -871,7 +670,6 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
           v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bh, v, 0, 0, 0);
           acc[pi][c][tg] = v;
         }
-#endif
         if constexpr (st < 3) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
         constexpr bool XFORM = st == 0;
         if constexpr (XFORM) __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
@@ -885,7 +683,6 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (st == 0) __syncthreads();               // everyone has read the raw stage
       });
-      }
       __builtin_amdgcn_s_waitcnt(0);                          // the DMA has landed
       __syncthreads();
     }
@@ -1366,14 +1163,6 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
   // IPDM_WBX3_C128=1 selects the 128-channel x 32-tile form.  Off by default: it wins 3-15 % per layer in isolation
   // (scripts/bench_conv.py) but loses 2.7 % on the whole iteration (26.07 vs 25.37 ms, same box, alternating runs) --
   // its doubled fragment traffic costs more clock under the sustained power limit than the halved VALU work returns.
-  static int use_spec = -1;                      // IPDM_WBX3_SPEC=1: wave-specialised form (conv_wino_bx3_spec.hip)
-  if (use_spec < 0) {
-    const char* e = getenv("IPDM_WBX3_SPEC");
-    use_spec = e ? atoi(e) : 0;
-  }
-  if (use_spec && wino_persist() && a.Cin >= 3 * X_KC && (small_dma || !small) && a.W % 4 == 0 &&
-      (reinterpret_cast<uintptr_t>(a.x) & 15) == 0)
-    return conv_wino_bx3_spec_launch(a, small_dma, cus_per_xcd(), s);
   static int use_c128 = -1;
   if (use_c128 < 0) {
     const char* e = getenv("IPDM_WBX3_C128");

@@ -1,11 +1,10 @@
 #!/usr/bin/env python3
-"""whole-workgroup cycle counts (s_memtime) of the persistent split-bf16 Winograd kernels: cycles per (tile, chunk) and the
-implied shader clock, for the symmetric kernel or the wave-specialised one (IPDM_WBX3_SPEC=1, IPDM_SPEC_PROBE=<mask>)"""
+"""whole-workgroup cycle counts (s_memtime) of the persistent split-bf16 Winograd kernel: cycles per (tile, chunk) and the
+implied shader clock.  Used with diagnostic builds (scripts/build_variant.sh) to price pieces of the kernel."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from inverseproblemwithdiffusionmodel_amd import ops, _lib
 B = 28
-spec = os.environ.get("IPDM_WBX3_SPEC") == "1"
 for ci, co, hw in [(128, 128, 128), (256, 256, 64)]:
     x = torch.randn(B, ci, hw, hw, device="cuda"); w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
     U = ops.conv_wino_bx3_weight(w)
@@ -20,10 +19,10 @@ for ci, co, hw in [(128, 128, 128), (256, 256, 64)]:
     t = buf.cpu().view(-1, 4)
     t = t[t[:, 0] != 0].double()
     tot = (t[:, 3] - t[:, 0])
-    px_per_tile = 128 if spec else 256
+    px_per_tile = 256
     tiles = B * hw * hw / px_per_tile * (co // 64)
     per_wg = tiles / t.shape[0]
     nch = ci // 16
-    mfma_bound = 48 * 32 if spec else 96 * 32
+    mfma_bound = 96 * 32
     print(f"{ci}->{co}@{hw}: {ms * 1e3:.0f} us, {t.shape[0]} workgroups x {per_wg:.1f} tiles; cycles/WG median {tot.median():.0f} max {tot.max():.0f}; "
           f"per (tile, chunk) {tot.median() / per_wg / nch:.0f} (MFMA-bound {mfma_bound}); implied clock {tot.max() / ms / 1e6:.2f} GHz")
