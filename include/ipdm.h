@@ -126,6 +126,11 @@ int ipdm_langevin_step_f32(float* x, const float* g, const float* noise, float s
 int ipdm_philox_normal_f32(float* out, uint64_t seed, int64_t sample_offset, int64_t step_id, int plane,
                            int64_t n_samples, int64_t sample_elems, void* stream);
 
+/* HOST function (no GPU): the 128 random bits behind elements 4*quad..4*quad+3 of (seed, sample, step_id, plane).
+ * key = seed, counter = (quad, step, sample, plane): distinct seeds / steps / samples never share a block
+ * (replaces torch.randn_like's device generator, ALD_optimizers.py:238-241, by a sharding-invariant stream). */
+int ipdm_philox_block_host(uint64_t seed, int64_t sample, int64_t step_id, int plane, uint32_t quad, uint32_t* out4);
+
 /* ------------------------------------------------------------------------------------------------
  * Score-network glue (reference: ncsn/models/normalization.py:150-176 InstanceNorm2dPlus;
  * ncsn/models/layers.py:11-23 get_act, :62-83 CRPBlock max-pool, :165-184 MSFBlock bilinear sum,

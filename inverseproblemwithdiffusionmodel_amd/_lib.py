@@ -34,6 +34,7 @@ SIGNATURES = {
                                 P, P, P, c_int, c_float, P, c_int, c_int, c_int, c_int, P],
     "ipdm_langevin_step_f32": [P, P, P, c_float, c_float, c_uint64, c_int64, c_int64, P, c_int64, c_int64, P],
     "ipdm_philox_normal_f32": [P, c_uint64, c_int64, c_int64, c_int, c_int64, c_int64, P],
+    "ipdm_philox_block_host": [c_uint64, c_int64, c_int64, c_int, ctypes.c_uint32, P],
     "ipdm_instnorm_plus_coef_f32": [P, P, P, P, P, c_int, c_int, c_int, P],
     "ipdm_affine_act_f32": [P, P, P, c_int, c_int, c_int, c_int, P],
     "ipdm_act_f32": [P, P, c_int64, c_int, P],

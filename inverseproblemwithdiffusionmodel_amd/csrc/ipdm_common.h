@@ -59,8 +59,10 @@ __device__ __forceinline__ double ipdm_wave_sum(double v) {
 }
 
 // ---- Philox4x32-10 counter-based generator --------------------------------------------------
-// counter = (element index lo, element index hi, sample id lo, sample id hi | plane<<31..),
-// key = (seed lo, seed hi) mixed with the step id; four uniforms -> four normals (Box-Muller).
+// key     = (seed lo, seed hi)                      -- the seed alone: two seeds never share a stream
+// counter = (quad index within the plane, step lo, sample id lo, plane | step bits 32..39 << 8 | sample id bits 32..47 << 16)
+// Every (seed, sample, step, plane, quad) is a distinct (key, counter) pair, so no two draws of one run, and no two
+// runs with different seeds, reuse a block.  Four uniforms -> four normals (Box-Muller).
 struct IpdmPhilox {
   uint32_t c[4];
   uint32_t k[2];
@@ -82,13 +84,22 @@ __host__ __device__ __forceinline__ void ipdm_philox4x32_10(uint32_t (&c)[4], ui
     k1 += 0xBB67AE85u;
   }
 }
+// the 128 random bits of quad `q` of plane `plane` of sample `sample` at step `step` (host + device: the host copy is
+// what ipdm_philox_block_host exposes to the CPU tests)
+__host__ __device__ __forceinline__ void ipdm_philox_block(uint64_t seed, int64_t sample, int64_t step, int plane,
+                                                           uint32_t q, uint32_t (&c)[4]) {
+  const uint64_t us = (uint64_t)sample, ut = (uint64_t)step;
+  c[0] = q;
+  c[1] = (uint32_t)ut;
+  c[2] = (uint32_t)us;
+  c[3] = ((uint32_t)plane & 0xffu) | (((uint32_t)(ut >> 32) & 0xffu) << 8) | (((uint32_t)(us >> 32) & 0xffffu) << 16);
+  ipdm_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
 // four standard normals for quad `q` (elements 4q..4q+3) of plane `plane` of sample `sample` at step `step`
 __device__ __forceinline__ void ipdm_philox_normal4(uint64_t seed, int64_t sample, int64_t step, int plane,
                                                     uint32_t q, float (&out)[4]) {
-  uint32_t c[4] = {q, (uint32_t)plane, (uint32_t)sample, (uint32_t)((uint64_t)sample >> 32)};
-  uint32_t k0 = (uint32_t)seed ^ (uint32_t)step;
-  uint32_t k1 = (uint32_t)(seed >> 32) ^ (uint32_t)((uint64_t)step >> 32) ^ 0x5851F42Du;
-  ipdm_philox4x32_10(c, k0, k1);
+  uint32_t c[4];
+  ipdm_philox_block(seed, sample, step, plane, q, c);
   const float two32 = 2.3283064365386963e-10f;                 // 2^-32
   float u0 = ((float)c[0] + 0.5f) * two32, u1 = ((float)c[1] + 0.5f) * two32;
   float u2 = ((float)c[2] + 0.5f) * two32, u3 = ((float)c[3] + 0.5f) * two32;

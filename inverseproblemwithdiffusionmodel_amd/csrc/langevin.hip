@@ -99,3 +99,14 @@ extern "C" int ipdm_philox_normal_f32(float* out, uint64_t seed, int64_t sample_
                      (long long)sample_elems);
   return ipdm_launch_status();
 }
+
+// host-side copy of the generator's integer stage (no GPU needed): the CPU tests check it against the published
+// Philox4x32-10 known-answer vectors and that different seeds / steps / samples never share a block
+extern "C" int ipdm_philox_block_host(uint64_t seed, int64_t sample, int64_t step_id, int plane, uint32_t quad,
+                                      uint32_t* out4) {
+  IPDM_REQUIRE(out4);
+  uint32_t c[4];
+  ipdm_philox_block(seed, sample, step_id, plane, quad, c);
+  for (int i = 0; i < 4; ++i) out4[i] = c[i];
+  return IPDM_OK;
+}

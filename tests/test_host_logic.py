@@ -27,6 +27,41 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.ipdm_build_arch() == b"gfx950"
 
 
+def _philox_block(seed, sample, step, plane, quad):
+    import ctypes
+    from inverseproblemwithdiffusionmodel_amd import _lib
+    out = (ctypes.c_uint32 * 4)()
+    assert _lib.lib.ipdm_philox_block_host(seed, sample, step, plane, quad, ctypes.cast(out, ctypes.c_void_p)) == 0
+    return tuple(out)
+
+
+def test_philox_known_answers_and_stream_independence():
+    """The integer stage of the Langevin noise generator (host copy of the device code): the published Philox4x32-10
+    known-answer vectors (Random123 kat_vectors: counter/key all-zero, all-ones, and the pi digits), and -- the
+    property the sampler needs -- no two (seed, step, sample, plane, quad) tuples share a block: in particular the
+    streams of seed 0 and seed 1 are disjoint (a key built as seed ^ step would make seed 1 replay seed 0's noise with
+    neighbouring steps swapped)."""
+    # counter (0,0,0,0), key (0,0): (quad, step, sample, plane) = 0, seed = 0
+    assert _philox_block(0, 0, 0, 0, 0) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+    # counter all ones, key all ones: quad = step lo = sample lo = 0xffffffff, plane byte | step hi byte | sample hi 16
+    assert _philox_block(0xffffffffffffffff, 0xffffffffffff, 0xffffffffff, 0xff, 0xffffffff) == \
+        (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+    # counter (243f6a88, 85a308d3, 13198a2e, 03707344), key (a4093822, 299f31d0)
+    seed = (0x299f31d0 << 32) | 0xa4093822
+    step = ((0x03707344 >> 8) & 0xff) << 32 | 0x85a308d3
+    sample = ((0x03707344 >> 16) & 0xffff) << 32 | 0x13198a2e
+    assert _philox_block(seed, sample, step, 0x44, 0x243f6a88) == (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+    seen = {}
+    for seed in (0, 1, 2, 3):
+        for step in range(64):
+            for sample in (0, 1, 13):
+                for plane in (0, 1):
+                    for quad in (0, 1, 4095):
+                        blk = _philox_block(seed, sample, step, plane, quad)
+                        assert blk not in seen, (seed, step, sample, plane, quad, seen.get(blk))
+                        seen[blk] = (seed, step, sample, plane, quad)
+
+
 def test_ops_reject_cpu_tensors():
     from inverseproblemwithdiffusionmodel_amd import ops
     from inverseproblemwithdiffusionmodel_amd.op import upfirdn2d, fused_leaky_relu

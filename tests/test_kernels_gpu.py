@@ -199,6 +199,11 @@ def test_langevin_and_philox(ops):
     part = ops.philox_normal((3, 128 * 128), "cuda", seed=11, sample_offset=4, step_id=5)
     assert torch.equal(full[4:7], part)
     assert not torch.equal(full[0], ops.philox_normal((1, 128 * 128), "cuda", seed=11, step_id=6)[0])
+    # seeds are independent streams: (seed 1, step s) never replays (seed 0, step s ^ 1) (XOR-folded key)
+    s0 = torch.stack([ops.philox_normal((2, 4096), "cuda", seed=0, step_id=s) for s in range(8)])
+    s1 = torch.stack([ops.philox_normal((2, 4096), "cuda", seed=1, step_id=s) for s in range(8)])
+    assert all(not torch.equal(s0[a], s1[b]) for a in range(8) for b in range(8))
+    assert float((s0[0] * s1[1]).mean().abs()) < 0.05 and float((s0[1] * s1[0]).mean().abs()) < 0.05
     assert abs(float(full.mean())) < 0.01 and abs(float(full.std()) - 1) < 0.01
     assert abs(float((full ** 4).mean()) - 3.0) < 0.1
     xd2 = dev(x.reshape(5, -1))
