@@ -267,7 +267,7 @@ def _sd(module, prefix):
     return {prefix + "__" + k.replace(".", "__"): npy(v) for k, v in module.state_dict().items()}
 
 
-def g07_layers():
+def g07_layers(write=True):
     out = {}
     torch.manual_seed(7)
     act = nn.ELU()
@@ -323,7 +323,8 @@ def g07_layers():
     out["net_labels"] = npy(labels)
     with torch.no_grad():
         out["net_y"] = npy(net(xin, labels))
-    save("g07_layers", **out)
+    if write:
+        save("g07_layers", **out)
     return net, cfg
 
 
