@@ -78,6 +78,8 @@ int ipdm_fft2c_c64(const float* in, float* out, int batch, int H, int W, int inv
 int64_t ipdm_fft2c_workspace_bytes(int batch, int H, int W);
 
 /* y[c][b] = mask * fft2c(S_c * x[b])        x [B][H][W] c64 -> y [n_coils][B][H][W] c64 */
+/* (sens == NULL with n_coils == 1: the single-coil operator RandomUndersamplingFourier.__call__, y = M F x,
+ *  undersampling_fourier.py:77-82) */
 int ipdm_sense_forward_c64(const float* x, const float* sens, const uint8_t* mask, int mask_t,
                            float* y, int B, int n_coils, int H, int W, void* stream);
 /* x[b] = sum_c S_c * ifft2c(mask? mask*s : s)    apply_mask == 0 reproduces SENSE.conj_op */
@@ -116,6 +118,26 @@ int ipdm_ald_sense_step_f32(float* x_re, float* x_im, const float* g_re, const f
                             const ipdm_sched_t* dev_sched /* device; non-NULL overrides step/noise_scale/coef/step_id */,
                             const float* y, const float* sens, const uint8_t* mask, int mask_t, float coef,
                             float* work /* [B][H][W] c64 scratch */, int B, int n_coils, int H, int W, void* stream);
+
+/* Single-coil data-consistency operators (A = M F, RandomUndersamplingFourier, no coil maps) on planar real/imag
+ * float32 [B][H][W], y [B][H][W] complex64; out may alias z.  mode:
+ *   0  L2Penalty on a single-coil operator (proximal_op.py:19-51): x = z - coef * F^-1[M (M F z - y)],
+ *      coef = 0.05 * (alpha/lamda) / B  (the .mean() of the reference's loss runs over the batch; computed by the caller)
+ *   1  SingleCoil closed form (proximal_op.py:72-94): x = F^-1[(F z + coef*y) / (1 + coef*M)], coef = alpha/lamda
+ *   2  RandomUndersamplingFourier.projection (undersampling_fourier.py:89-97) = Constrained.__call__ (proximal_op.py:62-69):
+ *      x = F^-1[coef*y + (1-coef) M F z + (1-M) F z], coef = lamda */
+int ipdm_singlecoil_prox_f32(const float* z_re, const float* z_im, const float* y, const uint8_t* mask, int mask_t,
+                             float coef, int mode, float* out_re, float* out_im, int B, int H, int W, void* stream);
+
+/* One fused Annealed-Langevin iteration tail for the single-coil samplers (the reference's
+ * scripts/acdc_inv_seg_sampling_keep_center_prox_real_imag.py:79-89 and cine_inv_sampling_keep_center_prox_real_imag.py:78-88
+ * build ALDInvSegProximalRealImag on RandomUndersamplingFourier + get_proximal(...)): Langevin update of both planes,
+ * then ipdm_singlecoil_prox_f32's operator `mode`, in place; scalars / noise as ipdm_ald_sense_step_f32. */
+int ipdm_ald_singlecoil_step_f32(float* x_re, float* x_im, const float* g_re, const float* g_im,
+                                 const float* noise_re, const float* noise_im,
+                                 float step, float noise_scale, uint64_t seed, int64_t sample_offset, int64_t step_id,
+                                 const ipdm_sched_t* dev_sched, const float* y, const uint8_t* mask, int mask_t,
+                                 float coef, int mode, int B, int H, int W, void* stream);
 
 /* Langevin update alone (ALD_optimizers.py:117): x += step*g + noise_scale*noise ; noise NULL -> Philox. */
 int ipdm_langevin_step_f32(float* x, const float* g, const float* noise, float step, float noise_scale,

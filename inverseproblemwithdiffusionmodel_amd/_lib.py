@@ -32,6 +32,9 @@ SIGNATURES = {
     "ipdm_sense_l2prox_f32": [P, P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_int, c_int, P],
     "ipdm_ald_sense_step_f32": [P, P, P, P, P, P, c_float, c_float, c_uint64, c_int64, c_int64, P,
                                 P, P, P, c_int, c_float, P, c_int, c_int, c_int, c_int, P],
+    "ipdm_singlecoil_prox_f32": [P, P, P, P, c_int, c_float, c_int, P, P, c_int, c_int, c_int, P],
+    "ipdm_ald_singlecoil_step_f32": [P, P, P, P, P, P, c_float, c_float, c_uint64, c_int64, c_int64, P,
+                                     P, P, c_int, c_float, c_int, c_int, c_int, c_int, P],
     "ipdm_langevin_step_f32": [P, P, P, c_float, c_float, c_uint64, c_int64, c_int64, P, c_int64, c_int64, P],
     "ipdm_philox_normal_f32": [P, c_uint64, c_int64, c_int64, c_int, c_int64, c_int64, P],
     "ipdm_philox_block_host": [c_uint64, c_int64, c_int64, c_int, ctypes.c_uint32, P],

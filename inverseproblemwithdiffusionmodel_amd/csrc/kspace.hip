@@ -198,10 +198,10 @@ __global__ __launch_bounds__(FFT_THREADS) void sense_forward_kernel(const float2
   const int HW = H * W;
   const int b = blockIdx.x, coil = blockIdx.y;
   const float2* src = x + (size_t)b * HW;
-  const float* sm = sens + (size_t)coil * HW;
+  const float* sm = sens ? sens + (size_t)coil * HW : nullptr;      // NULL: single coil, S = 1
   for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
     int r = e / W, c = e - r * W;
-    float s = sign_rc(r, c) * sm[e];
+    float s = sm ? sign_rc(r, c) * sm[e] : sign_rc(r, c);
     float2 v = src[e];
     L.buf[e] = make_float2(v.x * s, v.y * s);
   }
@@ -266,6 +266,31 @@ __global__ __launch_bounds__(FFT_THREADS) void sense_adjoint_kernel(const float2
   }
 }
 
+// Langevin update of one sample's two planes, in place (the first phase of the fused iteration tails):
+//   x += step*g + noise_scale*n, n injected (n_re/n_im) or Philox keyed by (seed, global sample id, step, plane)
+__device__ __forceinline__ void langevin_phase(float* xr, float* xi, const float* __restrict__ g_re,
+                                               const float* __restrict__ g_im, const float* __restrict__ n_re,
+                                               const float* __restrict__ n_im, float step, float noise_scale,
+                                               uint64_t seed, int64_t sample_offset, int64_t step_id, int b, int HW) {
+  for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+    size_t gi = (size_t)b * HW + e;
+    float nr, ni;
+    if (n_re) {
+      nr = n_re[gi];
+      ni = n_im[gi];
+    } else {
+      float q[4];
+      const int lane4 = e & 3;
+      ipdm_philox_normal4(seed, sample_offset + b, step_id, 0, (uint32_t)(e >> 2), q);
+      nr = lane4 == 0 ? q[0] : lane4 == 1 ? q[1] : lane4 == 2 ? q[2] : q[3];
+      ipdm_philox_normal4(seed, sample_offset + b, step_id, 1, (uint32_t)(e >> 2), q);
+      ni = lane4 == 0 ? q[0] : lane4 == 1 ? q[1] : lane4 == 2 ? q[2] : q[3];
+    }
+    xr[e] = xr[e] + step * g_re[gi] + nr * noise_scale;
+    xi[e] = xi[e] + step * g_im[gi] + ni * noise_scale;
+  }
+}
+
 // Langevin update (optional) + L2Penalty closed form, planar real/imag, in place.
 //   phase 0: z = x + step*g + noise_scale*n           -> stored back to x (global, L2-resident)
 //   per coil: LDS = S_c z ; FFT ; residual on sampled columns ; IFFT ; work += S_c * (.)
@@ -291,25 +316,8 @@ __global__ __launch_bounds__(FFT_THREADS) void ald_sense_step_kernel(
   float* xr = x_re + (size_t)b * HW;
   float* xi = x_im + (size_t)b * HW;
   float2* wk = work + (size_t)b * HW;
-  if constexpr (LANGEVIN) {
-    for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
-      size_t gi = (size_t)b * HW + e;
-      float nr, ni;
-      if (n_re) {
-        nr = n_re[gi];
-        ni = n_im[gi];
-      } else {
-        float q[4];
-        const int lane4 = e & 3;
-        ipdm_philox_normal4(seed, sample_offset + b, step_id, 0, (uint32_t)(e >> 2), q);
-        nr = lane4 == 0 ? q[0] : lane4 == 1 ? q[1] : lane4 == 2 ? q[2] : q[3];
-        ipdm_philox_normal4(seed, sample_offset + b, step_id, 1, (uint32_t)(e >> 2), q);
-        ni = lane4 == 0 ? q[0] : lane4 == 1 ? q[1] : lane4 == 2 ? q[2] : q[3];
-      }
-      xr[e] = xr[e] + step * g_re[gi] + nr * noise_scale;
-      xi[e] = xi[e] + step * g_im[gi] + ni * noise_scale;
-    }
-  }
+  if constexpr (LANGEVIN)
+    langevin_phase(xr, xi, g_re, g_im, n_re, n_im, step, noise_scale, seed, sample_offset, step_id, b, HW);
   if (coef == 0.f) return;
   // pass 2c: forward transform of S_c z ; pass 2c+1: inverse transform of the masked residual
   for (int pass = 0; pass < 2 * n_coils; ++pass) {
@@ -363,6 +371,85 @@ __global__ __launch_bounds__(FFT_THREADS) void ald_sense_step_kernel(
   }
 }
 
+// Single-coil iteration tail (RandomUndersamplingFourier: A = M F, no coil maps), planar real/imag, in place:
+// Langevin update (optional) + one of the reference's three single-coil data-consistency operators
+//   mode 0  L2Penalty   x = z - coef * F^-1[ M (M F z - y) ]               (proximal_op.py:19-51, coef = 0.05 a/(l K), K = B)
+//   mode 1  SingleCoil  x = F^-1[ (F z + coef*y) / (1 + coef*M) ]          (proximal_op.py:72-94, coef = alpha/lamda)
+//   mode 2  projection  x = F^-1[ coef*y + (1-coef) M F z + (1-M) F z ]   (undersampling_fourier.py:89-97, coef = lamda)
+// The image stays in LDS between the two transforms; z is re-read from x (L2-resident) for mode 0.
+template <bool LANGEVIN>
+__global__ __launch_bounds__(FFT_THREADS) void ald_singlecoil_step_kernel(
+    float* x_re, float* x_im, const float* __restrict__ g_re, const float* __restrict__ g_im,
+    const float* __restrict__ n_re, const float* __restrict__ n_im, float step, float noise_scale, uint64_t seed,
+    int64_t sample_offset, int64_t step_id, const ipdm_sched_t* __restrict__ sched, const float2* __restrict__ y,
+    const uint8_t* __restrict__ mask, int mask_t, float coef, int mode, int B, int H, int W) {
+  FFT_LDS_SETUP(H, W)
+  if (sched) {
+    step = sched->step;
+    noise_scale = sched->noise_scale;
+    coef = sched->coef;
+    step_id = sched->step_id;
+  }
+  const int HW = H * W;
+  const int b = blockIdx.x;
+  const float scale = rsqrtf((float)HW);
+  float* xr = x_re + (size_t)b * HW;
+  float* xi = x_im + (size_t)b * HW;
+  if constexpr (LANGEVIN)
+    langevin_phase(xr, xi, g_re, g_im, n_re, n_im, step, noise_scale, seed, sample_offset, step_id, b, HW);
+  if (mode == 0 && coef == 0.f) return;
+  for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+    int r = e / W, c = e - r * W;
+    float sg = sign_rc(r, c);
+    L.buf[e] = make_float2(xr[e] * sg, xi[e] * sg);
+  }
+  __syncthreads();
+  fft2_lds(L, H, W, false);
+  // k-space value K = sg*scale*v; the inverse transform wants sg*K' -> every formula is written on scale*v and sg*y
+  const float2* yb = y + (size_t)b * HW;
+  for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+    int r = e / W, c = e - r * W;
+    float2 v = L.buf[e];
+    v.x *= scale;
+    v.y *= scale;
+    const bool m = mask_at(mask, mask_t, b, W, c);
+    float2 o;
+    if (mode == 0) {
+      o = make_float2(0.f, 0.f);
+      if (m) {
+        float sg = sign_rc(r, c);
+        float2 yy = yb[e];
+        o = make_float2(v.x - sg * yy.x, v.y - sg * yy.y);
+      }
+    } else if (mode == 1) {
+      float sg = sign_rc(r, c) * coef;
+      float2 yy = yb[e];
+      float inv = m ? 1.f / (1.f + coef) : 1.f;
+      o = make_float2((v.x + sg * yy.x) * inv, (v.y + sg * yy.y) * inv);
+    } else {
+      float sg = sign_rc(r, c) * coef;
+      float2 yy = yb[e];
+      float keep = m ? 1.f - coef : 1.f;
+      o = make_float2(sg * yy.x + keep * v.x, sg * yy.y + keep * v.y);
+    }
+    L.buf[e] = o;
+  }
+  __syncthreads();
+  fft2_lds(L, H, W, true);
+  for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+    int r = e / W, c = e - r * W;
+    float2 v = L.buf[e];
+    float w = sign_rc(r, c) * scale;
+    if (mode == 0) {
+      xr[e] = xr[e] - coef * (v.x * w);
+      xi[e] = xi[e] - coef * (v.y * w);
+    } else {
+      xr[e] = v.x * w;
+      xi[e] = v.y * w;
+    }
+  }
+}
+
 template <typename K>
 static int set_lds_limit(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return IPDM_OK;
@@ -405,7 +492,7 @@ extern "C" int ipdm_sense_forward_c64(const float* x, const float* sens, const u
                                       int B, int n_coils, int H, int W, void* stream) {
   IPDM_REQUIRE(B >= 0 && n_coils > 0 && H > 0 && W > 0 && mask_t > 0);
   if (B == 0) return IPDM_OK;
-  IPDM_REQUIRE(x && sens && mask && y);
+  IPDM_REQUIRE(x && mask && y && (sens || n_coils == 1));
   if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
   size_t lds = lds_bytes(H, W);
   int rc = set_lds_limit(sense_forward_kernel, lds);
@@ -481,5 +568,44 @@ extern "C" int ipdm_ald_sense_step_f32(float* x_re, float* x_im, const float* g_
                      g_re, g_im, noise_re, noise_im, step, noise_scale, seed, (long long)sample_offset,
                      (long long)step_id, dev_sched, reinterpret_cast<const float2*>(y), sens, mask, mask_t, coef,
                      reinterpret_cast<float2*>(work), B, n_coils, H, W);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_singlecoil_prox_f32(const float* z_re, const float* z_im, const float* y, const uint8_t* mask,
+                                        int mask_t, float coef, int mode, float* out_re, float* out_im, int B, int H,
+                                        int W, void* stream) {
+  IPDM_REQUIRE(B >= 0 && H > 0 && W > 0 && mask_t > 0 && mode >= 0 && mode <= 2);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(z_re && z_im && y && mask && out_re && out_im);
+  if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
+  hipStream_t st = ipdm_stream(stream);
+  const size_t bytes = (size_t)B * H * W * sizeof(float);
+  if (out_re != z_re && hipMemcpyAsync(out_re, z_re, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
+  if (out_im != z_im && hipMemcpyAsync(out_im, z_im, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
+  size_t lds = lds_bytes(H, W);
+  int rc = set_lds_limit(ald_singlecoil_step_kernel<false>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ald_singlecoil_step_kernel<false>, dim3(B), dim3(FFT_THREADS), lds, st, out_re, out_im, nullptr,
+                     nullptr, nullptr, nullptr, 0.f, 0.f, 0ull, 0ll, 0ll, nullptr, reinterpret_cast<const float2*>(y), mask,
+                     mask_t, coef, mode, B, H, W);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_ald_singlecoil_step_f32(float* x_re, float* x_im, const float* g_re, const float* g_im,
+                                            const float* noise_re, const float* noise_im, float step, float noise_scale,
+                                            uint64_t seed, int64_t sample_offset, int64_t step_id,
+                                            const ipdm_sched_t* dev_sched, const float* y, const uint8_t* mask, int mask_t,
+                                            float coef, int mode, int B, int H, int W, void* stream) {
+  IPDM_REQUIRE(B >= 0 && H > 0 && W > 0 && mask_t > 0 && mode >= 0 && mode <= 2);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x_re && x_im && g_re && g_im && y && mask);
+  IPDM_REQUIRE((noise_re == nullptr) == (noise_im == nullptr));
+  if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
+  size_t lds = lds_bytes(H, W);
+  int rc = set_lds_limit(ald_singlecoil_step_kernel<true>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ald_singlecoil_step_kernel<true>, dim3(B), dim3(FFT_THREADS), lds, ipdm_stream(stream), x_re, x_im,
+                     g_re, g_im, noise_re, noise_im, step, noise_scale, seed, (long long)sample_offset,
+                     (long long)step_id, dev_sched, reinterpret_cast<const float2*>(y), mask, mask_t, coef, mode, B, H, W);
   return ipdm_launch_status();
 }

@@ -94,7 +94,7 @@ class IterationRunner:
         self.levels = lv
         self.table_dev = torch.from_numpy(table.view(np.uint8).reshape(L * n_each, -1).copy()).to(dev)
         self.label_table = torch.arange(L, device=dev)[:, None].repeat(1, 2 * B)
-        self.st = dict(x=self.x, B=B, y=meas, sens=s.linear_tfm.sens_f32(dev), mask=s.linear_tfm.mask_u8(dev),
+        self.st = dict(x=self.x, B=B, y=meas, sc_mode=None, sens=s.linear_tfm.sens_f32(dev), mask=s.linear_tfm.mask_u8(dev),
                        work=torch.empty(B * H * W * 2, dtype=torch.float32, device=dev),
                        labels=torch.zeros(2 * B, dtype=torch.long, device=dev), noise_re=None, noise_im=None,
                        seed=seed, sample_offset=sample_offset,

@@ -55,22 +55,23 @@ class RandomUndersamplingFourier(LinearTransform):
         return self._dev[key]
 
     def __call__(self, X: torch.Tensor) -> torch.Tensor:
+        """S = mask * i2k_complex(X): one kernel (FFT in LDS, mask applied on the way out)"""
         _check_gpu(X, "RandomUndersamplingFourier")
-        K = i2k_complex(X)
-        return K * self._mask_like(K)
-
-    def _mask_like(self, K):
-        return self.mask.to(K.device)
+        X = X.to(torch.complex64)
+        return ops.sense_forward(X, None, self.mask_u8(X.device))[0]
 
     def conj_op(self, S: torch.Tensor) -> torch.Tensor:
         return k2i_complex(S)
 
     def projection(self, X: torch.Tensor, S: torch.Tensor, lamda: float) -> torch.Tensor:
-        # the reference's `(1 - mask)` raises for its own bool masks; the documented formula is applied
-        mask = self.mask.to(X.device).to(torch.float32)
-        S_from_X = i2k_complex(X)
-        mixed = lamda * S + (1 - lamda) * mask * S_from_X
-        return k2i_complex(mixed + (1 - mask) * S_from_X)
+        """k-space mix F^-1[lamda S + (1 - lamda) M F X + (1 - M) F X] (:89-97).  The reference's `(1 - mask)` raises for
+        its own bool masks; the documented formula is applied, as one kernel."""
+        _check_gpu(X, "RandomUndersamplingFourier.projection")
+        zr = torch.view_as_real(X.to(torch.complex64))
+        o_re, o_im = ops.singlecoil_prox(zr[..., 0].contiguous(), zr[..., 1].contiguous(),
+                                         S.to(torch.complex64).contiguous(), self.mask_u8(X.device), float(lamda),
+                                         ops.SC_PROJECTION)
+        return torch.complex(o_re, o_im)
 
 
 class SENSE(LinearTransform):

@@ -29,7 +29,7 @@ import torch
 
 from ... import ops
 from .proximal_op import Proximal, L2Penalty, Constrained, SingleCoil  # noqa: F401
-from ..linear_transforms.undersampling_fourier import SENSE
+from ..linear_transforms.undersampling_fourier import SENSE, RandomUndersamplingFourier
 from ...helpers.utils import data_transform, reshape_temporal_dim
 from ..linear_transforms.finite_diff import FiniteDiff
 
@@ -162,23 +162,40 @@ class ALDInvSegProximalRealImag(ALDOptimizer):
     def _iteration(self, st):
         grad = self.scorenet(st["x"], st["labels"])
         B = st["B"]
-        ops.ald_sense_step(st["x"][:B], st["x"][B:], grad[:B], grad[B:], st["y"], st["sens"], st["mask"], st["work"],
-                           noise_re=st["noise_re"], noise_im=st["noise_im"], seed=st["seed"],
-                           sample_offset=st["sample_offset"], dev_sched=st["sched_dev"])
+        if st["sc_mode"] is None:            # multi-coil SENSE + L2Penalty
+            ops.ald_sense_step(st["x"][:B], st["x"][B:], grad[:B], grad[B:], st["y"], st["sens"], st["mask"], st["work"],
+                               noise_re=st["noise_re"], noise_im=st["noise_im"], seed=st["seed"],
+                               sample_offset=st["sample_offset"], dev_sched=st["sched_dev"])
+        else:                                # single-coil RandomUndersamplingFourier + L2Penalty / SingleCoil
+            ops.ald_singlecoil_step(st["x"][:B], st["x"][B:], grad[:B], grad[B:], st["y"], st["mask"], st["sc_mode"],
+                                    noise_re=st["noise_re"], noise_im=st["noise_im"], seed=st["seed"],
+                                    sample_offset=st["sample_offset"], dev_sched=st["sched_dev"])
 
     def _check_fast_path(self, kwargs):
-        if not isinstance(self.proximal, L2Penalty) or not isinstance(self.linear_tfm, SENSE):
-            raise NotImplementedError("the fused iteration covers L2Penalty + SENSE (the shipped ACDC/CINE setting); "
-                                      f"got {type(self.proximal).__name__} + {type(self.linear_tfm).__name__}")
+        """-> sc_mode: None for SENSE + L2Penalty, the ipdm_singlecoil_prox_f32 mode for the single-coil operators
+        (the reference's acdc_inv_seg_sampling_keep_center_prox_real_imag.py:79-89 / cine_inv_sampling_...:78-88)"""
         if self.seg is not None and bool((self.lh_weights != 0).any()):
             raise NotImplementedError("segmentation-likelihood guidance with non-zero weight is not built yet "
                                       "(SURVEY.md 8f rank 1); use seg_start_time=1 or seg=None")
+        if isinstance(self.linear_tfm, SENSE):
+            if isinstance(self.proximal, L2Penalty):
+                return None
+        elif isinstance(self.linear_tfm, RandomUndersamplingFourier):
+            if isinstance(self.proximal, L2Penalty):
+                return ops.SC_L2PENALTY
+            if isinstance(self.proximal, SingleCoil):
+                return ops.SC_CLOSED_FORM
+        if isinstance(self.proximal, Constrained):
+            # the reference's samplers call proximal(x, y, coeff, 1.) (:315); Constrained.__call__ takes (X, S, lamda)
+            raise TypeError("Constrained.__call__() takes 4 positional arguments but 5 were given")
+        raise NotImplementedError(f"no fused iteration for {type(self.proximal).__name__} + "
+                                  f"{type(self.linear_tfm).__name__}")
 
     @torch.no_grad()
     def __call__(self, **kwargs):
         """kwargs: label, lamda, save_dir, lr_scaled, seg_mode (+ noise_fn, seed, sample_offset, verbose, use_graph,
         n_levels/start_level to run a slice of the schedule)"""
-        self._check_fast_path(kwargs)
+        sc_mode = self._check_fast_path(kwargs)
         sigmas = self.sigmas
         n_steps_each, step_lr = self.params["n_steps_each"], self.params["step_lr"]
         denoise = self.params["denoise"]
@@ -200,8 +217,9 @@ class ALDInvSegProximalRealImag(ALDOptimizer):
         lv0 = kwargs.get("start_level", 0)
         lv1 = L if kwargs.get("n_levels") is None else min(L, lv0 + kwargs["n_levels"])
 
-        st = dict(x=x, B=B, y=meas, sens=lin.sens_f32(dev), mask=lin.mask_u8(dev),
-                  work=torch.empty(B * H * W * 2, dtype=torch.float32, device=dev),
+        st = dict(x=x, B=B, y=meas, sc_mode=sc_mode, sens=lin.sens_f32(dev) if sc_mode is None else None,
+                  mask=lin.mask_u8(dev),
+                  work=torch.empty(B * H * W * 2, dtype=torch.float32, device=dev) if sc_mode is None else None,
                   labels=torch.zeros(2 * B, dtype=torch.long, device=dev),
                   noise_re=None, noise_im=None, seed=kwargs.get("seed", 0),
                   sample_offset=kwargs.get("sample_offset", 0),

@@ -138,8 +138,8 @@ class NCSNv2(_NCSNv2Base):
         self.res1 = self._stage(ngf, ngf)
         self.res2 = self._stage(ngf, 2 * ngf, 'down')
         self.res3 = self._stage(2 * ngf, 2 * ngf, 'down', dilation=2)
-        if config.data.image_size == 28:
-            raise NotImplementedError("the 28-pixel adjust_padding branch (ncsnv2.py:50-56) is unused by shipped configs")
+        # the reference's 28-pixel branch (ncsnv2.py:50-56) passes adjust_padding=True to a DILATED block, whose
+        # constructor ignores it (layers.py:410-414): both branches build the same modules (pinned by g23 'v2_28')
         self.res4 = self._stage(2 * ngf, 2 * ngf, 'down', dilation=4)
         self.refine1 = RefineBlock([2 * ngf], 2 * ngf, act=self.act, start=True)
         self.refine2 = RefineBlock([2 * ngf, 2 * ngf], 2 * ngf, act=self.act)

@@ -7,11 +7,19 @@ runs over the (num_sens, W) axes that .sum(dim=(1,2,3)) leaves) and K = B for a 
 (pinned by tests/golden/g05_prox.npz).  That closed form runs as one fused HIP kernel."""
 import torch
 
-from ..linear_transforms import LinearTransform, i2k_complex, k2i_complex
+from ..linear_transforms import LinearTransform
 from ..linear_transforms.undersampling_fourier import RandomUndersamplingFourier, SENSE
 from ... import ops
 
 SGD_LR = 5e-2
+
+
+def _singlecoil(lin_tfm, z, y, coef, mode):
+    """z, y (B, C, H, W) complex -> the single-coil operator `mode` of ipdm_singlecoil_prox_f32"""
+    zr = torch.view_as_real(z.to(torch.complex64))
+    o_re, o_im = ops.singlecoil_prox(zr[..., 0].contiguous(), zr[..., 1].contiguous(),
+                                     y.to(torch.complex64).contiguous(), lin_tfm.mask_u8(z.device), coef, mode)
+    return torch.complex(o_re, o_im)
 
 
 class Proximal(object):
@@ -44,9 +52,7 @@ class L2Penalty(Proximal):
                                           self.lin_tfm.sens_f32(z.device), self.lin_tfm.mask_u8(z.device), c)
             return torch.complex(o_re, o_im)
         if isinstance(self.lin_tfm, RandomUndersamplingFourier):
-            mask = self.lin_tfm.mask.to(z.device)
-            r = (i2k_complex(z) * mask - y) * mask
-            return z - c * k2i_complex(r)
+            return _singlecoil(self.lin_tfm, z, y, c, ops.SC_L2PENALTY)
         raise NotImplementedError(f"L2Penalty: no kernel chain for {type(self.lin_tfm).__name__}")
 
     @torch.no_grad()
@@ -69,11 +75,13 @@ class SingleCoil(Proximal):
         assert isinstance(self.lin_tfm, RandomUndersamplingFourier), "only supporting RandomUnversamplingFourier"
 
     def __call__(self, z, y, alpha, lamda):
-        """closed form  x = F' diag(1 / (1 + alpha M)) F (z + alpha F' y)"""
-        alpha = alpha / lamda
-        mask = self.lin_tfm.mask.to(z.device)
-        x = i2k_complex(z + alpha * k2i_complex(y))
-        return k2i_complex(x * (1 / (1 + mask * alpha)))
+        """closed form  x = F' diag(1 / (1 + alpha M)) F (z + alpha F' y), one kernel (two LDS-resident FFTs)"""
+        if not z.is_cuda:
+            raise RuntimeError("SingleCoil: expected GPU tensors (no CPU fallback in this build)")
+        return _singlecoil(self.lin_tfm, z, y, self.coef(float(alpha), float(lamda), z.shape), ops.SC_CLOSED_FORM)
+
+    def coef(self, alpha, lamda, z_shape=None):
+        return alpha / lamda
 
     @torch.no_grad()
     def check_solution(self, x_out, z, y, alpha, lamda):

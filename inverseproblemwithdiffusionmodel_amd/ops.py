@@ -30,6 +30,19 @@ def _ptr(t):
     return P(t.data_ptr()) if t is not None else P(0)
 
 
+def _inplace_operand(t, dtype, name):
+    """operand of an in-place / raw-pointer kernel: must already be a contiguous GPU tensor of the kernel's dtype
+    (a silent .contiguous() copy would make the kernel update the copy; a wrong dtype would be read as raw memory)"""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"ipdm: {name} must be a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"ipdm: {name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"ipdm: {name} must be contiguous (in-place kernel operand; call .contiguous() yourself and "
+                         "keep the result)")
+    return t
+
+
 def _stream():
     return P(torch.cuda.current_stream().cuda_stream)
 
@@ -90,10 +103,11 @@ def _mask_u8(mask, W, device):
 
 
 def sense_forward(x, sens_f32, mask_u8):
+    """sens_f32 None: single coil (S = 1), returns y with a leading axis of length 1"""
     x = _gpu(x, torch.complex64, "x")
     B = x.numel() // (x.shape[-1] * x.shape[-2])
     H, W = x.shape[-2:]
-    n = sens_f32.shape[0]
+    n = 1 if sens_f32 is None else sens_f32.shape[0]
     y = torch.empty((n,) + tuple(x.shape), dtype=torch.complex64, device=x.device)
     call("ipdm_sense_forward_c64", _ptr(x), _ptr(sens_f32), _ptr(mask_u8), mask_u8.shape[0], _ptr(y), B, n, H, W,
          _stream())
@@ -137,17 +151,63 @@ def sense_l2prox(z_re, z_im, y, sens_f32, mask_u8, coef, out_re=None, out_im=Non
 def ald_sense_step(x_re, x_im, g_re, g_im, y, sens_f32, mask_u8, work, step=0.0, noise_scale=0.0, coef=0.0,
                    noise_re=None, noise_im=None, seed=0, sample_offset=0, step_id=0, dev_sched=None):
     """in place on x_re / x_im.  dev_sched: uint8/any device tensor holding an ipdm_sched_t."""
+    for t, n in ((x_re, "x_re"), (x_im, "x_im"), (g_re, "g_re"), (g_im, "g_im"), (sens_f32, "sens")):
+        _inplace_operand(t, torch.float32, n)
+    _inplace_operand(y, torch.complex64, "y")
+    for t, n in ((noise_re, "noise_re"), (noise_im, "noise_im")):
+        if t is not None:
+            _inplace_operand(t, torch.float32, n)
     H, W = x_re.shape[-2:]
     B = x_re.numel() // (H * W)
+    if g_re.numel() != x_re.numel() or g_im.numel() != x_im.numel() or y.numel() != sens_f32.shape[0] * B * H * W:
+        raise ValueError("ald_sense_step: operand sizes do not match the state")
     call("ipdm_ald_sense_step_f32", _ptr(x_re), _ptr(x_im), _ptr(g_re), _ptr(g_im), _ptr(noise_re), _ptr(noise_im),
          float(step), float(noise_scale), int(seed), int(sample_offset), int(step_id), _ptr(dev_sched),
          _ptr(y), _ptr(sens_f32), _ptr(mask_u8), mask_u8.shape[0], float(coef), _ptr(work), B, sens_f32.shape[0], H, W,
          _stream())
 
 
+SC_L2PENALTY, SC_CLOSED_FORM, SC_PROJECTION = 0, 1, 2
+
+
+def singlecoil_prox(z_re, z_im, y, mask_u8, coef, mode, out_re=None, out_im=None):
+    """single-coil data consistency on planar real / imaginary planes (modes: ipdm.h, ipdm_singlecoil_prox_f32)"""
+    z_re, z_im = _gpu(z_re, torch.float32, "z_re"), _gpu(z_im, torch.float32, "z_im")
+    y = _gpu(y, torch.complex64, "y")
+    H, W = z_re.shape[-2:]
+    B = z_re.numel() // (H * W)
+    if y.numel() != B * H * W:
+        raise ValueError(f"singlecoil_prox: measurement {tuple(y.shape)} does not match the image batch {tuple(z_re.shape)}")
+    out_re = torch.empty_like(z_re) if out_re is None else out_re
+    out_im = torch.empty_like(z_im) if out_im is None else out_im
+    call("ipdm_singlecoil_prox_f32", _ptr(z_re), _ptr(z_im), _ptr(y), _ptr(mask_u8), mask_u8.shape[0], float(coef),
+         int(mode), _ptr(out_re), _ptr(out_im), B, H, W, _stream())
+    return out_re, out_im
+
+
+def ald_singlecoil_step(x_re, x_im, g_re, g_im, y, mask_u8, mode, step=0.0, noise_scale=0.0, coef=0.0, noise_re=None,
+                        noise_im=None, seed=0, sample_offset=0, step_id=0, dev_sched=None):
+    """in place on x_re / x_im (contiguous float32 GPU planes)"""
+    for t, n in ((x_re, "x_re"), (x_im, "x_im"), (g_re, "g_re"), (g_im, "g_im")):
+        _inplace_operand(t, torch.float32, n)
+    _inplace_operand(y, torch.complex64, "y")
+    H, W = x_re.shape[-2:]
+    B = x_re.numel() // (H * W)
+    call("ipdm_ald_singlecoil_step_f32", _ptr(x_re), _ptr(x_im), _ptr(g_re), _ptr(g_im), _ptr(noise_re), _ptr(noise_im),
+         float(step), float(noise_scale), int(seed), int(sample_offset), int(step_id), _ptr(dev_sched), _ptr(y),
+         _ptr(mask_u8), mask_u8.shape[0], float(coef), int(mode), B, H, W, _stream())
+
+
 def langevin_step(x, g, step=0.0, noise_scale=0.0, noise=None, seed=0, sample_offset=0, step_id=0, dev_sched=None):
     """x += step*g + noise_scale*noise in place; x [n_samples, ...]."""
-    x = _gpu(x, torch.float32, "x")
+    _inplace_operand(x, torch.float32, "x")
+    _inplace_operand(g, torch.float32, "g")
+    if noise is not None:
+        _inplace_operand(noise, torch.float32, "noise")
+        if noise.numel() != x.numel():
+            raise ValueError("langevin_step: noise does not match x")
+    if g.numel() != x.numel():
+        raise ValueError("langevin_step: g does not match x")
     n_samples = x.shape[0]
     call("ipdm_langevin_step_f32", _ptr(x), _ptr(g), _ptr(noise), float(step), float(noise_scale), int(seed),
          int(sample_offset), int(step_id), _ptr(dev_sched), n_samples, x.numel() // max(n_samples, 1), _stream())
@@ -567,7 +627,10 @@ def wino_bx3_pays(Cin, Cout, H, W, dilation=1, B=1):
 
 def adam_ascent(x, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8):
     """one torch.optim.Adam step in place on x with param.grad = -g (x, g, m, v: same-shaped float32 GPU tensors)"""
-    x = _gpu(x, torch.float32, "x")
+    for t, n in ((x, "x"), (g, "g"), (m, "m"), (v, "v")):
+        _inplace_operand(t, torch.float32, n)
+        if t.numel() != x.numel():
+            raise ValueError(f"adam_ascent: {n} does not match x")
     call("ipdm_adam_ascent_f32", _ptr(x), _ptr(g), _ptr(m), _ptr(v), x.numel(), float(lr), float(betas[0]), float(betas[1]),
          float(eps), int(step), _stream())
     return x

@@ -160,3 +160,101 @@ def test_map2dtime_golden(golden, net3d, mode):
     diff = np.abs(x - ref)
     assert (diff > 0.02 * n_it * lr).mean() < 0.005 and diff.max() < n_it * lr
     assert metrics.nrmse(np.abs(x), np.abs(ref)) < 1e-3
+
+
+def test_full_size_ncsn3d_shallow_vs_reference(golden):
+    """the full temporal prior of config 4 (cine127_1d.yml: ngf 128, 8x8 = 64 channels, T = 24; 61.9 M parameters) against
+    the reference's own forward on synthetic weights (g21): 3-D dilated convolutions, temporal stride-2 / transposed
+    convolutions, MaxPool3d at production widths"""
+    from inverseproblemwithdiffusionmodel_amd.ncsn.models.ncsn3d import NCSN3DShallow
+    from inverseproblemwithdiffusionmodel_amd.synthetic import synth_state_dict
+    g = golden("g21_full3d")
+    c = tiny_config(ngf=128, num_classes=400, sigma_begin=40, sigma_end=0.01)
+    c.data.channels, c.data.channels_3d, c.data.image_size = 64, 1, 24
+    net = NCSN3DShallow(c)
+    keys = list(net.state_dict().keys())
+    assert keys == list(g["key_names"])
+    assert [",".join(map(str, v.shape)) for v in net.state_dict().values()] == list(g["key_shapes"])
+    assert sum(p.numel() for p in net.parameters()) == int(g["n_params"])
+    net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=0), strict=False)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["labels"]).cuda()).cpu().numpy()
+    ref = g["y"]
+    assert y.shape == ref.shape == (3, 64, 24)
+    assert np.abs(y - ref).max() <= 2e-4 * np.abs(ref).max()
+    assert metrics.nrmse(y, ref) < 1e-4
+
+
+def test_finite_diff_golden(golden):
+    """FiniteDiff forward / adjoint / TV sub-gradient on the GPU vs the reference's own vectors (g11)"""
+    from inverseproblemwithdiffusionmodel_amd.ncsn.linear_transforms.finite_diff import FiniteDiff
+    g = golden("g11_temporal")
+    fd = FiniteDiff(2)
+    v = torch.from_numpy(g["fd_x"]).cuda()
+    assert torch.equal(fd(v).cpu(), torch.from_numpy(g["fd_fwd"]))
+    assert torch.equal(fd.conj_op(v).cpu(), torch.from_numpy(g["fd_adj"]))
+    np.testing.assert_allclose(fd.log_lh_grad(v, lamda=0.3).cpu().numpy(), g["fd_tvgrad"], atol=1e-7)
+    # adjointness <D x, s> = <x, D^T s>
+    s_ = torch.randn(v.shape, generator=torch.Generator().manual_seed(3)).cuda()
+    assert abs(float((fd(v) * s_).sum() - (v * fd.conj_op(s_)).sum())) < 1e-4
+
+
+class _SeededNoiseR2:
+    def __init__(self, seed):
+        self.g, self.calls, self.total = torch.Generator().manual_seed(seed), 0, 0.0
+
+    def __call__(self, like):
+        n = torch.randn(like.shape, generator=self.g, dtype=torch.float32)
+        self.calls += 1
+        self.total += float(n.double().sum())
+        return n
+
+
+@pytest.mark.parametrize("tag,mode,shift", [("shift", "diffusion1d", True), ("d1only", "diffusion1d-only", False),
+                                            ("tvonly", "tv-only", False)])
+def test_ald2dtime_shift_and_only_modes_golden(golden, net3d, tag, mode, shift):
+    """ALD2DTime(if_random_shift=True): one np.random.randint patch shift per temporal step, shared by the batch
+    (ALD_optimizers.py:472) -- same host RNG stream as the reference run (np.random.seed(251)), shifts recorded in the
+    fixture; and the '*-only' modes, which swap the spatial schedule for the temporal one and skip the spatial step
+    (:357-361).  Reference trajectories: g25."""
+    from inverseproblemwithdiffusionmodel_amd.ncsn.models import ncsnv2, ALD_optimizers, proximal_op
+    from inverseproblemwithdiffusionmodel_amd.ncsn.linear_transforms.undersampling_fourier import SENSE
+    g7, g17, g = golden("g07_layers"), golden("g17_ald2dtime"), golden("g25_ald2dtime_x")
+    net2d = ncsnv2.NCSNv2Deepest(tiny_config())
+    net2d.load_state_dict(state_dict_from_golden(g7, "net"), strict=True)
+    net2d = net2d.cuda().eval()
+    op = SENSE("exp", 4, 8, 0.04, (1, H, W), seed=0)
+    sigmas = torch.from_numpy(g17["sigmas"]).cuda()
+    sigmas_T = torch.from_numpy(g17["sigmas_T"] if tag == "shift" else g["sigmas_T12"]).cuda()
+    params = dict(n_steps_each=2, step_lr=2e-5, denoise=False, final_only=True)
+    meas = torch.from_numpy(g17["measurement"]).cuda()
+    sampler = ALD_optimizers.ALD2DTime(proximal_op.get_proximal("L2Penalty")(op), net3d, sigmas_T, (1, T, 1, H, W), net2d,
+                                       sigmas, params, tiny_config(), meas, op, device=torch.device("cuda"))
+    lamda_T, n_calls, n_sum = g[f"{tag}_meta"]
+    noise = _SeededNoiseR2(250)
+    drawn = []
+    real_randint = np.random.randint
+
+    def randint(*a, **k):
+        v = real_randint(*a, **k)
+        drawn.append(np.array(v))
+        return v
+    np.random.seed(251)
+    np.random.randint = randint
+    try:
+        x = sampler(save_dir=None, lr_scaled=1.0e5, mode_T=mode, lamda_T=float(lamda_T), if_random_shift=shift,
+                    noise_fn=noise)[0].numpy()
+    finally:
+        np.random.randint = real_randint
+    assert noise.calls == int(n_calls) and abs(noise.total - float(n_sum)) < 1e-3
+    if shift:
+        assert np.array_equal(np.stack(drawn), g["shift_shifts"]) and len(drawn) == 16     # integer logic: bit-exact
+    else:
+        assert not drawn
+    ref = g[f"{tag}_x"]
+    assert x.shape == ref.shape == (1, T, 1, H, W)
+    assert metrics.nrmse(np.abs(x), np.abs(ref)) < 1e-3
+    for t in range(T):
+        assert abs(metrics.ssim(np.abs(x[0, t, 0]), np.abs(ref[0, t, 0])) - 1) < 1e-3
+    np.testing.assert_allclose(x, ref, atol=2e-3)

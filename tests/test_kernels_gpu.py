@@ -152,6 +152,90 @@ def test_l2prox_golden(ops, golden):
         np.testing.assert_allclose(got, p[f"l2_sense_{i}_x"], atol=3e-6)
 
 
+def test_singlecoil_ops_golden(ops, golden):
+    """RandomUndersamplingFourier __call__ / conj_op, its L2Penalty branch (K = B) and the SingleCoil closed form against
+    the reference's own outputs (g05 sc_*), through the product classes and through the raw kernels"""
+    from inverseproblemwithdiffusionmodel_amd.ncsn.linear_transforms.undersampling_fourier import RandomUndersamplingFourier
+    from inverseproblemwithdiffusionmodel_amd.ncsn.models.proximal_op import get_proximal
+    g4, p = golden("g04_sense"), golden("g05_prox")
+    sc = RandomUndersamplingFourier(8, 0.04, (1, 32, 32), seed=2)
+    assert np.array_equal(sc.mask.numpy(), p["sc_mask"])                                  # bit-exact mask
+    x, z = dev(g4["x"]), dev(p["z"])
+    y = sc(x)
+    np.testing.assert_allclose(y.cpu().numpy(), p["sc_y"], atol=5e-6)
+    np.testing.assert_allclose(sc.conj_op(dev(p["sc_y"])).cpu().numpy(), p["sc_Ax_adj"], atol=5e-6)
+    got = get_proximal("L2Penalty")(sc)(z, dev(p["sc_y"]), 0.9, 1.0).cpu().numpy()
+    np.testing.assert_allclose(got, p["l2_sc_x"], atol=3e-6)
+    assert np.abs(p["l2_sc_x"] - p["z"]).max() > 1e-3                                    # the update is visible
+    a, l = p["singlecoil_alpha_lamda"]
+    prox = get_proximal("SingleCoil")(sc)
+    xs = prox(z, dev(p["sc_y"]), float(a), float(l))
+    np.testing.assert_allclose(xs.cpu().numpy(), p["singlecoil_x"], atol=5e-6)
+    assert float(prox.check_solution(xs, z, dev(p["sc_y"]), float(a), float(l))) < 1e-8   # reference: p["singlecoil_check"]
+    # raw kernel, planar, in place (out aliases z), vs the oracle
+    m8 = dev(p["sc_mask"].reshape(1, 32).astype(np.uint8))
+    zr, zi = dev(p["z"].real), dev(p["z"].imag)
+    ops.singlecoil_prox(zr, zi, dev(p["sc_y"]), m8, float(a / l), ops.SC_CLOSED_FORM, out_re=zr, out_im=zi)
+    want = kspace.single_coil(p["z"], p["sc_y"], a, l, p["sc_mask"])
+    np.testing.assert_allclose(zr.cpu().numpy() + 1j * zi.cpu().numpy(), want, atol=5e-6)
+    # projection (Constrained): F^-1[lamda S + (1-lamda) M F X + (1-M) F X] for an arbitrary S
+    S = g4["s"][0]
+    lam = 0.3
+    k = kspace.fft2c(p["z"])
+    m = p["sc_mask"]
+    want = kspace.ifft2c(lam * S + (1 - lam) * m * k + (1 - m) * k)
+    got = get_proximal("Constrained")(sc)(z, dev(S), lam).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=5e-6)
+    with pytest.raises(RuntimeError):
+        sc(torch.zeros(1, 1, 32, 32, dtype=torch.complex64))                             # no CPU path
+
+
+def test_ald_singlecoil_step_matches_oracle(ops):
+    """fused Langevin + single-coil data consistency at 128x128 (both proximals) vs the oracle; Philox path == injected"""
+    rng = np.random.default_rng(16)
+    H = W = 128
+    B = 3
+    mask = kspace.generate_mask(1, W, seed=0, **kspace.MASK_PARAMS["R8"])
+    img = (rng.random((1, 1, H, W)) * np.exp(1j * rng.standard_normal((1, 1, H, W)))).astype(np.complex64)
+    y = np.repeat((mask * kspace.fft2c(img)).astype(np.complex64), B, axis=0)
+    x = (rng.standard_normal((B, 1, H, W)) + 1j * rng.standard_normal((B, 1, H, W))).astype(np.complex64)
+    g = rng.standard_normal((2, B, 1, H, W)).astype(np.float32)
+    n = rng.standard_normal((2, B, 1, H, W)).astype(np.float32)
+    step, ns = np.float32(0.21), np.float32(np.sqrt(2 * 0.21))
+    z = ((x.real + step * g[0] + n[0] * ns) + 1j * (x.imag + step * g[1] + n[1] * ns)).astype(np.complex64)
+    m8 = dev(mask.astype(np.uint8))
+    for mode, alpha, want in [(ops.SC_L2PENALTY, 30.0, kspace.l2_penalty_single(z, y, 30.0, 1.0, mask)),
+                              (ops.SC_CLOSED_FORM, 0.7, kspace.single_coil(z, y, 0.7, 1.0, mask))]:
+        coef = 0.05 * alpha / B if mode == ops.SC_L2PENALTY else alpha
+        x_re, x_im = dev(x.real), dev(x.imag)
+        ops.ald_singlecoil_step(x_re, x_im, dev(g[0]), dev(g[1]), dev(y), m8, mode, step=float(step),
+                                noise_scale=float(ns), coef=coef, noise_re=dev(n[0]), noise_im=dev(n[1]))
+        got = x_re.cpu().numpy() + 1j * x_im.cpu().numpy()
+        assert np.abs(want - z).max() > 1e-2
+        np.testing.assert_allclose(got, want, atol=1e-5)
+    # Philox noise: the fused kernel draws what ipdm_philox_normal_f32 reports for (seed, sample, step, plane)
+    x_re, x_im = dev(x.real), dev(x.imag)
+    ops.ald_singlecoil_step(x_re, x_im, dev(g[0]), dev(g[1]), dev(y), m8, ops.SC_L2PENALTY, step=float(step),
+                            noise_scale=float(ns), coef=0.0, seed=9, sample_offset=4, step_id=77)
+    nr = ops.philox_normal((B, H * W), "cuda", seed=9, sample_offset=4, step_id=77, plane=0).cpu().numpy().reshape(B, 1, H, W)
+    np.testing.assert_allclose(x_re.cpu().numpy(), x.real + step * g[0] + nr * ns, atol=2e-6)
+    with pytest.raises(ValueError):
+        ops.ald_singlecoil_step(x_re[:, :, :, ::2], x_im, dev(g[0]), dev(g[1]), dev(y), m8, 0)   # strided in-place operand
+
+
+def test_inplace_wrappers_reject_bad_operands(ops):
+    """in-place kernels must not silently update a contiguous copy nor read a wrong dtype as raw memory"""
+    x = torch.zeros(2, 8, 8, device="cuda")
+    with pytest.raises(ValueError):
+        ops.langevin_step(x.transpose(1, 2), torch.zeros(2, 8, 8, device="cuda"), 0.1, 0.1, noise=torch.zeros(2, 8, 8, device="cuda"))
+    with pytest.raises(TypeError):
+        ops.langevin_step(x, torch.zeros(2, 8, 8, device="cuda", dtype=torch.float64), 0.1, 0.1)
+    with pytest.raises(ValueError):
+        ops.langevin_step(x, torch.zeros(2, 8, 4, device="cuda"), 0.1, 0.1)
+    with pytest.raises(TypeError):
+        ops.adam_ascent(x, x.double(), x.clone(), x.clone(), 1e-3, 1)
+
+
 def test_ald_sense_step_matches_oracle(ops):
     rng = np.random.default_rng(6)
     H = W = 128

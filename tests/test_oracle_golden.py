@@ -1,6 +1,7 @@
 """Pin the CPU oracle against the reference's own outputs (tests/golden/*.npz, produced by
 tests/golden/make_golden.py importing /root/reference).  CPU only."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -271,3 +272,36 @@ def test_map_sense_golden(golden, tag):
     # a handful of pixels differ by up to 1 % of the distance travelled (50 * lr); the image metric is the gate
     np.testing.assert_allclose(x, ref, atol=0.02 * 50 * float(g[f"{tag}_lr"]))
     assert metrics.nrmse(np.abs(x), np.abs(ref)) < 1e-3
+
+
+@pytest.mark.skipif(os.environ.get("IPDM_SLOW_TESTS") != "1", reason="~2 min per case on 8 cores; set IPDM_SLOW_TESTS=1")
+@pytest.mark.parametrize("tag", ["tail_dc", "tail_default", "mid_default"])
+def test_oracle_fullsize_trajectory_vs_reference(golden, tag):
+    """the CPU oracle at the HEADLINE size (NCSNv2Deepest ngf 128, 128x128, R=40, 4 coils) against the reference's own
+    12-level trajectories (g20): pins oracle/scorenet.py + oracle/ald.py + oracle/kspace.py at full size (opt-in: slow)"""
+    from inverseproblemwithdiffusionmodel_amd.synthetic import synth_state_dict
+    g = golden("g20_fullsize_ald")
+    lv0, lr_scaled, seed, n_calls, n_sum = g[f"{tag}_meta"]
+    lv0 = int(lv0)
+    shapes = {k: tuple(int(v) for v in s.split(",") if v) for k, s in zip(golden("g15_fullnet")["key_names"],
+                                                                        golden("g15_fullnet")["key_shapes"])}
+    sd = synth_state_dict(shapes, seed=0)
+    sig_all = kspace.get_sigmas(348, 0.01, 2311)
+    sd["sigmas"] = torch.from_numpy(sig_all)
+    maps = kspace.sens_maps(4, 128, 128, 0)
+    meas = np.repeat(g["measurement_1"], 2, axis=1)
+    gen = torch.Generator().manual_seed(int(seed))
+    noise = lambda like: torch.randn(like.shape, generator=gen, dtype=torch.float32)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        x = ald.ald_sense_real_imag(lambda x_, lab: scorenet.ncsnv2_deepest(x_, lab + lv0, sd), sig_all[lv0:lv0 + 12],
+                                           meas, maps, g["mask"], 9e-7, 3, float(lr_scaled), True, noise)
+    ref = g[f"{tag}_x"]
+    x0 = kspace.sense_adjoint(meas, maps)
+    print(tag, "max|x-ref|", np.abs(x - ref).max(), "scale", np.abs(ref).max(),
+          "upd rel", np.linalg.norm((x - x0) - (ref - x0)) / np.linalg.norm(ref - x0),
+          "upd/x0", np.linalg.norm(ref - x0) / np.linalg.norm(x0))
+    for b in range(2):
+        assert metrics.nrmse(np.abs(x[b]), np.abs(ref[b])) < 1e-3
+    np.testing.assert_allclose(x, ref, atol=1e-3 * np.abs(ref).max())
+    assert np.linalg.norm((x - x0) - (ref - x0)) <= 2e-3 * np.linalg.norm(ref - x0)

@@ -145,3 +145,53 @@ def test_groupnorm_swish_vs_torch(B, C, G, H, W):
     coef = ops.groupnorm_coef(x.cuda(), w.cuda(), b.cuda(), G, eps=1e-6)
     got = ops.affine_act(x.cuda(), coef, ops.ACT_SWISH).cpu().double()
     assert (got - want).abs().max() < 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_full_size_ncsnpp_256_vs_reference(golden):
+    """config 5's network at its real size (celebahq_256 VE: nf 128, ch_mult (1,1,2,2,2,2,2), attention at 16 px, FIR
+    up/down-sampling on the upfirdn2d kernel, progressive input/output skips; 65.57 M parameters) at 256x256 against the
+    reference's own forward (g22; output stored at stride 2 + float64 moments of the whole tensor)"""
+    from inverseproblemwithdiffusionmodel_amd.configs import ve_ncsnpp
+    from inverseproblemwithdiffusionmodel_amd.models import ncsnpp
+    from inverseproblemwithdiffusionmodel_amd.synthetic import synth_state_dict
+    g = golden("g22_ncsnpp256")
+    cfg = ve_ncsnpp.get_config()
+    cfg.device = torch.device("cuda")
+    net = ncsnpp.NCSNpp(cfg)
+    assert list(net.state_dict().keys()) == list(g["key_names"])
+    assert [",".join(map(str, v.shape)) for v in net.state_dict().values()] == list(g["key_shapes"])
+    assert sum(p.numel() for p in net.parameters()) == int(g["n_params"])
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=0)
+    for k in g["fourier_W_key"]:                 # the frozen Gaussian Fourier frequencies, as make_golden_r2.py drew them
+        k = str(k)
+        sd[k] = torch.randn(net.state_dict()[k].shape, generator=torch.Generator().manual_seed(22)) * cfg.model.fourier_scale
+    net.load_state_dict(sd, strict=False)
+    net = net.cuda().eval()
+    gen = torch.Generator().manual_seed(220)
+    x = torch.rand(1, 3, 256, 256, generator=gen) + 2.0 * torch.randn(1, 3, 256, 256, generator=gen)
+    with torch.no_grad():
+        y = net(x.cuda(), torch.from_numpy(g["sigma"]).cuda()).cpu()
+    ref = g["y_s2"]
+    s_, ss_, mx = g["y_moments"]
+    assert np.abs(y[:, :, ::2, ::2].numpy() - ref).max() <= 5e-4 * mx
+    yd = y.double()
+    assert abs(float(yd.sum()) - s_) <= 1e-4 * np.sqrt(ss_ * yd.numel()) and abs(float((yd * yd).sum()) / ss_ - 1) < 1e-4
+    assert abs(float(yd.abs().max()) / mx - 1) < 1e-3
+
+
+@pytest.mark.parametrize("tag,kw", [("rk45", dict(rtol=1e-3, atol=1e-3, method="RK45", denoise=True)),
+                                    ("rk23", dict(rtol=1e-2, atol=1e-2, method="RK23", denoise=False))])
+def test_ode_sampler_golden(net, golden, tag, kw):
+    """probability-flow ODE sampler (sde/sampling.py:419-490: scipy solve_ivp on the host, drift = one NCSN++ evaluation per
+    function call) from the stored latent code vs the reference's run on the same tiny NCSN++ (g24).  The adaptive step
+    controller sees fp32 round-off, so the function-evaluation count is compared with a small allowance."""
+    from inverseproblemwithdiffusionmodel_amd.sde import sde_lib, sampling
+    g = golden("g24_ode")
+    sde = sde_lib.VESDE(sigma_min=0.01, sigma_max=50.0, N=20)
+    shape = (2, 3, 32, 32)
+    fn = sampling.get_ode_sampler(sde, shape, lambda v: v, eps=1e-3, device="cuda", **kw)
+    x, nfe = fn(net, z=torch.from_numpy(g["z"]).cuda())
+    ref = g[f"{tag}_x"]
+    assert abs(int(nfe) - int(g[f"{tag}_nfe"])) <= 12
+    tol = 2 * (kw["rtol"] * np.abs(ref).max() + kw["atol"])           # the solver's own accuracy target bounds the comparison
+    assert np.abs(x.cpu().numpy() - ref).max() <= tol

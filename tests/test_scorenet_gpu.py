@@ -196,6 +196,176 @@ def test_philox_run_is_shard_invariant(pkg, tiny_net, golden):
     assert not torch.equal(a, b)
 
 
+class _SeededNoise:
+    """the generator make_golden_r2.py used: randn(like.shape) call after call from Generator().manual_seed(seed)"""
+
+    def __init__(self, seed):
+        self.g, self.calls, self.total = torch.Generator().manual_seed(int(seed)), 0, 0.0
+
+    def __call__(self, like):
+        n = torch.randn(like.shape, generator=self.g, dtype=torch.float32)
+        self.calls += 1
+        self.total += float(n.double().sum())
+        return n
+
+
+class _LabelOffset(torch.nn.Module):
+    """the window onto the 2311-level network the fixture used: net(x, labels + offset)"""
+
+    def __init__(self, net, offset):
+        super().__init__()
+        self.net, self.offset = net, offset
+
+    def forward(self, x, labels):
+        return self.net(x, labels + self.offset)
+
+
+@pytest.fixture(scope="module")
+def full_net(pkg):
+    from inverseproblemwithdiffusionmodel_amd.synthetic import synth_state_dict
+    cfg = tiny_config(ngf=128, num_classes=2311, sigma_begin=348, sigma_end=0.01)
+    cfg.data.image_size = 128
+    net = pkg.ncsnv2.NCSNv2Deepest(cfg)
+    net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=0), strict=False)
+    return cfg, net.cuda().eval()
+
+
+@pytest.mark.parametrize("tag,use_graph", [("tail_dc", True), ("tail_dc", False), ("tail_default", True),
+                                           ("mid_default", True), ("mid_default", False)])
+def test_headline_trajectory_vs_reference(pkg, golden, full_net, tag, use_graph):
+    """THE headline configuration (128x128 complex, R = 40, 4 coils, NCSNv2Deepest ngf 128 = 94.1 M parameters, L2Penalty)
+    against the REFERENCE's own ALDInvSegProximalRealImag runs (tests/golden/g20_fullsize_ald.npz): 12 noise levels x 3
+    Langevin + proximal iterations + the denoising step under the same seeded noise stream, at the tail of the schedule
+    (lr_scaled 2e6 and the script default 1) and in mid-schedule (sigma ~ 2.4: noise and score steps are O(0.1..1) of the
+    image).  Everything that only runs at full size is in the loop: dilated Winograd at 16 px, split-K, the persistent
+    LDS-DMA kernel, the batch-dependent dispatch, the hipGraph replay.  Tolerance: north_star's NRMSE / SSIM 1e-3 per
+    sample, plus elementwise bounds on the reconstruction AND on the update x - x_init (so that a wrong network could not
+    hide behind a small step)."""
+    cfg, net = full_net
+    g = golden("g20_fullsize_ald")
+    lv0, lr_scaled, seed, n_calls, n_sum = g[f"{tag}_meta"]
+    lv0 = int(lv0)
+    B, H, W = 2, 128, 128
+    op = pkg.uf.SENSE("exp", 4, 40, 0.04, (1, H, W), seed=0)
+    assert np.array_equal(op.random_under_fourier.mask.numpy(), g["mask"])                 # bit-exact R=40 mask
+    from oracle import kspace as okspace
+    sig_all = torch.from_numpy(okspace.get_sigmas(348, 0.01, 2311))
+    sig = sig_all[lv0:lv0 + 12].clone().cuda()
+    meas = torch.from_numpy(g["measurement_1"]).repeat(1, B, 1, 1, 1).cuda()
+    params = dict(n_steps_each=3, step_lr=9e-7, denoise=True, final_only=True)
+    sampler = pkg.ald.ALDInvSegProximalRealImag(pkg.prox.get_proximal("L2Penalty")(op), 1.0, "linear", (B, 1, H, W),
+                                                _LabelOffset(net, lv0), sig, params, cfg, meas, op, seg=None,
+                                                device=torch.device("cuda"))
+    noise = _SeededNoise(seed)
+    x = sampler(label=None, lamda=0.1, save_dir=None, lr_scaled=float(lr_scaled), seg_mode="full", noise_fn=noise,
+                use_graph=use_graph)[0].numpy()
+    assert noise.calls == int(n_calls) == 72 and abs(noise.total - float(n_sum)) < 1e-2     # the reference's stream
+    ref = g[f"{tag}_x"]
+    assert x.shape == ref.shape == (B, 1, H, W) and np.isfinite(x).all()
+    x0 = op.conj_op(meas).cpu().numpy()
+    upd, upd_ref = x - x0, ref - x0
+    scale = np.abs(ref).max()
+    for b in range(B):
+        assert metrics.nrmse(np.abs(x[b]), np.abs(ref[b])) < 1e-3
+        assert abs(metrics.ssim(np.abs(x[b, 0]), np.abs(ref[b, 0])) - 1.0) < 1e-3
+    np.testing.assert_allclose(x, ref, atol=1e-3 * scale)
+    # the update itself: relative l2 error of (x - x_init) against the reference's
+    assert np.linalg.norm(upd - upd_ref) <= 2e-3 * np.linalg.norm(upd_ref)
+    assert np.linalg.norm(upd_ref) > 0.05 * np.linalg.norm(x0)                              # the run moved the image
+
+
+@pytest.mark.parametrize("name,cls,size", [("v2_32", "NCSNv2", 32), ("v2_28", "NCSNv2", 28), ("deeper_32", "NCSNv2Deeper", 32)])
+def test_ncsnv2_variants_golden(pkg, golden, name, cls, size):
+    """NCSNv2 (incl. the 28-pixel branch of ncsnv2.py:50-56 = BASELINE config 1's literal size) and NCSNv2Deeper vs the
+    reference's forwards; weights = synth_state_dict(seed=231) on the reference's own key/shape list"""
+    from inverseproblemwithdiffusionmodel_amd.synthetic import synth_state_dict
+    g = golden("g23_variants")
+    cfg = tiny_config(ngf=4, num_classes=10)
+    cfg.data.image_size = size
+    net = getattr(pkg.ncsnv2, cls)(cfg)
+    keys = [f"{k}:{','.join(map(str, v.shape))}" for k, v in net.state_dict().items()]
+    assert keys == list(g[f"{name}_keys"])
+    net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=231), strict=False)
+    net = net.cuda().eval()
+    y = net(torch.from_numpy(g[f"{name}_x"]).cuda(), torch.from_numpy(g[f"{name}_labels"]).cuda()).cpu().numpy()
+    ref = g[f"{name}_y"]
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("name,cls", [("sde64", "NCSNv2"), ("sde128", "NCSNv2_128"), ("sde256", "NCSNv2_256")])
+def test_score_sde_ncsnv2_adapters(golden, name, cls):
+    """score_sde flavour (models/ncsnv2.py:43-416): ConfigDict schema, the reference classes' state-dict keys/shapes and
+    float sigma table; forward pinned to the architecture the classes state (their ncsn-side twins on the same weights),
+    because the reference's own forward raises at the first dilated block at every size (fixture flag, see
+    make_golden_r2.py g23)."""
+    from inverseproblemwithdiffusionmodel_amd.configs import ConfigDict
+    from inverseproblemwithdiffusionmodel_amd.models import ncsnv2 as sde_ncsnv2, utils as mutils
+    from inverseproblemwithdiffusionmodel_amd.synthetic import synth_state_dict
+    g = golden("g23_variants")
+    assert bool(g[f"{name}_reference_forward_raises"])
+    size, centered, nf, scales, smax, smin = g[f"{name}_cfg"]
+    c = ConfigDict()
+    c.data = ConfigDict(image_size=int(size), centered=bool(centered), channels=1, num_channels=1)
+    c.model = ConfigDict(nf=int(nf), num_scales=int(scales), sigma_max=float(smax), sigma_min=float(smin),
+                         normalization="InstanceNorm++", nonlinearity="elu")
+    c.device = torch.device("cuda")
+    net = getattr(sde_ncsnv2, cls)(c)
+    assert mutils.get_model({"sde64": "ncsnv2_64", "sde128": "ncsnv2_128", "sde256": "ncsnv2_256"}[name]) is getattr(sde_ncsnv2, cls)
+    keys = [f"{k}:{','.join(map(str, v.shape))}" for k, v in net.state_dict().items()]
+    assert sorted(keys) == sorted(g[f"{name}_keys"])
+    np.testing.assert_allclose(net.sigmas.cpu().numpy(), g[f"{name}_sigmas"], rtol=1e-6)
+    net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=234), strict=False)
+    net = net.cuda().eval()
+    y = net(torch.from_numpy(g[f"{name}_x"]).cuda(), torch.from_numpy(g[f"{name}_labels"]).cuda()).float().cpu().numpy()
+    ref = g[f"{name}_y"]
+    assert np.abs(y - ref).max() <= 1e-4 * np.abs(ref).max()
+    # get_network picks the class by image size (models/ncsnv2.py:31-40)
+    for sz, want in [(64, "NCSNv2"), (128, "NCSNv2_128"), (256, "NCSNv2_256")]:
+        c.data.image_size = sz
+        assert sde_ncsnv2.get_network(c).func is getattr(sde_ncsnv2, want)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("tag,prox_name", [("l2_dc", "L2Penalty"), ("l2_default", "L2Penalty"),
+                                           ("closed_dc", "SingleCoil"), ("closed_default", "SingleCoil")])
+def test_singlecoil_trajectory_golden(pkg, tiny_net, golden, tag, prox_name, use_graph):
+    """single-coil sampler (scripts/acdc_inv_seg_sampling_keep_center_prox_real_imag.py:79-89: RandomUndersamplingFourier +
+    get_proximal(...)) vs the reference's own 30-step + denoise trajectories (g26), fused single-coil iteration tail"""
+    g = golden("g26_singlecoil")
+    sc = pkg.uf.RandomUndersamplingFourier(8, 0.04, (1, 32, 32), seed=2)
+    assert np.array_equal(sc.mask.numpy(), g["mask"])
+    lr_scaled, n_calls, n_sum = g[f"{tag}_meta"]
+    sigmas = torch.from_numpy(g["sigmas"]).cuda()
+    params = dict(n_steps_each=3, step_lr=9e-7, denoise=True, final_only=True)
+    meas = torch.from_numpy(g["measurement"]).cuda()
+    sampler = pkg.ald.ALDInvSegProximalRealImag(pkg.prox.get_proximal(prox_name)(sc), 1.0, "linear", (2, 1, 32, 32),
+                                                tiny_net, sigmas, params, tiny_config(), meas, sc, seg=None,
+                                                device=torch.device("cuda"))
+    noise = _SeededNoise(260)
+    x = sampler(label=None, lamda=0.1, save_dir=None, lr_scaled=float(lr_scaled), seg_mode="full", noise_fn=noise,
+                use_graph=use_graph)[0].numpy()
+    assert noise.calls == int(n_calls) and abs(noise.total - float(n_sum)) < 1e-3
+    ref = g[f"{tag}_x"]
+    for b in range(2):
+        assert metrics.nrmse(np.abs(x[b]), np.abs(ref[b])) < 1e-3
+        assert abs(metrics.ssim(np.abs(x[b, 0]), np.abs(ref[b, 0])) - 1.0) < 1e-3
+    np.testing.assert_allclose(x, ref, atol=1e-3)
+    if tag.endswith("_dc"):
+        assert np.abs(ref - g[tag.replace("_dc", "_default") + "_x"]).max() > 1e-2         # data consistency is visible
+
+
+def test_sampler_rejects_unbuilt_combinations(pkg, tiny_net, golden):
+    g = golden("g26_singlecoil")
+    sc = pkg.uf.RandomUndersamplingFourier(8, 0.04, (1, 32, 32), seed=2)
+    mk = lambda prox: pkg.ald.ALDInvSegProximalRealImag(
+        prox, 1.0, "linear", (2, 1, 32, 32), tiny_net, torch.from_numpy(g["sigmas"]).cuda(),
+        dict(n_steps_each=3, step_lr=9e-7, denoise=True, final_only=True), tiny_config(),
+        torch.from_numpy(g["measurement"]).cuda(), sc, seg=None, device=torch.device("cuda"))
+    with pytest.raises(TypeError):                 # the reference's 4-argument proximal call cannot take Constrained
+        mk(pkg.prox.get_proximal("Constrained")(sc))(lr_scaled=1.0)
+
+
 def test_full_size_trajectory_bf16x3_vs_fp32_mfma():
     """The headline workload (128x128, R = 40, 4 coils, ngf-128 network, L2Penalty) over the LAST 12 noise levels
     (36 Langevin + proximal iterations and the denoising step, Philox noise): the split-bf16 kernel family and the
