@@ -1,15 +1,18 @@
 // upfirdn2d + fused bias/activation for gfx950.
 //
-// Both ops are HBM-bound (4*(in+out) bytes per upfirdn2d call, 8 bytes/element for
-// bias-act).  upfirdn2d stages one input tile (+halo) per workgroup in LDS with coalesced row loads,
-// keeps the flipped, zero-extended FIR taps in LDS, and lets each thread produce several outputs of
-// one (plane, tile); only the polyphase taps that hit a non-inserted sample are visited.  Anything
-// outside the specialised (up, down, taps<=4) modes takes a generic one-thread-per-output kernel
-// with the reference's clamped tap ranges.
+// Both ops are HBM-bound (4*(in+out) bytes per upfirdn2d call, 8 bytes/element for bias-act).
+// upfirdn2d has three kernels:
+//   * upfirdn2d_stream_kernel -- the shapes NCSN++ issues (2x FIR down / up-sampling, 4x4 taps, float4-shaped rows): no LDS,
+//     taps in SGPRs, a rolling window of input rows in registers, only 16-byte (8-byte for the up-sampler's window)
+//     lane accesses, polyphase tap selection at compile time; 5.2-5.4 TB/s on the 335 MB down-sampling call, 4.9-5.9 TB/s
+//     on the up-sampling calls (scripts/bench_resample.py, B = 8; profiles/r02_*)
+//   * upfirdn2d_tiled_kernel  -- other (up, down) in {1,2} with <= 4x4 taps: one input tile (+halo) per workgroup in LDS
+//   * upfirdn2d_generic_kernel -- anything else, one thread per output with the reference's clamped tap ranges.
 //
 // Semantics follow op/upfirdn2d.py:168-209 (upfirdn2d_native) / op/upfirdn2d_kernel.cu:49-105 and
 // op/fused_bias_act_kernel.cu:19-49 of the reference.
 #include "ipdm_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -82,6 +85,157 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// MI355X-first FIR resampler for the shapes NCSN++ issues (minor == 1, 4x4 taps zero-extended, rows of whole float4s).
+// No LDS: a thread owns OW consecutive output columns and walks RS output rows down the image, keeping a rolling
+// window of NR input rows x NW aligned float4s in registers.  Every global access is a 16-byte lane access
+// (global_load_dwordx4 / global_store_dwordx4); the window's outer float4s overlap the neighbouring lanes' and are
+// served by L1.  The window rotates through NR register slots by phase (no register moves): PH = NR / gcd(NR, ADV)
+// row groups are unrolled per loop trip.  Tap -> window-element indices are compile-time, so the zero-inserted
+// samples of the up-sampler are never multiplied (polyphase) and everything stays in VGPRs.
+//   out[oy][ox] = sum_{ky,kx} upz[oy*DOWN + ky - PY0][ox*DOWN + kx - PX0] * w[ky][kx],  w = flipped kernel,
+//   upz[u][v] = in[u/UP][v/UP] where both are multiples of UP, else 0          (op/upfirdn2d.py:168-209)
+__host__ __device__ constexpr int cfloor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+__host__ __device__ constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+
+template <int UP, int DOWN, int PX0, int PY0, int OW_>
+struct FirGeom {
+  static constexpr int K = 4;
+  static constexpr int OW = OW_;                                                // output columns per thread (whole float4s)
+  static constexpr int IB = OW * DOWN / UP;                                     // input columns per thread
+  static constexpr int VW = IB % 4 == 0 ? 4 : 2;                                // floats per aligned window load
+  static constexpr int F0 = cfloor_div(UP - 1 - PX0, UP);                       // first input column, relative
+  static constexpr int L0 = cfloor_div((OW - 1) * DOWN + K - 1 - PX0, UP);      // last input column, relative
+  static constexpr int WA = VW * cfloor_div(F0, VW);                            // aligned window start, relative
+  static constexpr int NW = (L0 - WA) / VW + 1;                                 // vector loads per window row
+  static constexpr int OG = UP;                                                 // output rows per row group
+  static constexpr int RF = cfloor_div(UP - 1 - PY0, UP);                       // first / last input row of a group,
+  static constexpr int RL = cfloor_div((OG - 1) * DOWN + K - 1 - PY0, UP);      // relative to g*DOWN
+  static constexpr int NR = RL - RF + 1;
+  static constexpr int ADV = DOWN;                                              // input rows per group
+  static constexpr int PH = NR / cgcd(NR, ADV);
+  static_assert(IB % 2 == 0 && (OW * DOWN) % UP == 0, "thread base must stay vector-aligned");
+  static_assert(OW % 4 == 0 && NR > ADV, "unsupported geometry");
+};
+
+template <int UP, int DOWN, int PX0, int PY0, int OW_>
+__global__ __launch_bounds__(256) void upfirdn2d_stream_kernel(const float* __restrict__ in,
+                                                               const float* __restrict__ kernel,
+                                                               float* __restrict__ out, int planes, int in_h, int in_w,
+                                                               int out_h, int out_w, int kernel_h, int kernel_w,
+                                                               int rows_per_thread) {
+  using G = FirGeom<UP, DOWN, PX0, PY0, OW_>;
+  constexpr int K = G::K, OW = G::OW, NW = G::NW, VW = G::VW, NR = G::NR, OG = G::OG, ADV = G::ADV, PH = G::PH;
+  // flipped, zero-extended taps -> SGPRs (uniform loads)
+  float w[K][K];
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx)
+    {   // unconditional scalar load from a clamped index, then select (no branch per tap)
+      const float t = kernel[max(kernel_h - 1 - ky, 0) * kernel_w + max(kernel_w - 1 - kx, 0)];
+      w[ky][kx] = (ky < kernel_h && kx < kernel_w) ? t : 0.f;
+    }
+
+  const int nq = (out_w + OW - 1) / OW;                       // column groups per row
+  const int groups_total = (out_h + OG - 1) / OG;             // row groups per plane
+  const int gps = rows_per_thread;                            // row groups per strip (per thread)
+  const int ns = (groups_total + gps - 1) / gps;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;          // the host keeps planes*ns*nq below 2^31
+  if (idx >= (unsigned)planes * (unsigned)ns * (unsigned)nq) return;
+  const unsigned row_item = idx / (unsigned)nq;
+  const int tx = (int)(idx - row_item * (unsigned)nq);
+  const int plane = (int)(row_item / (unsigned)ns);
+  const int strip = (int)(row_item - (unsigned)plane * (unsigned)ns);
+  const float* src = in + (size_t)plane * in_h * in_w;
+  float* dst = out + (size_t)plane * out_h * out_w;
+  const int g0 = strip * gps;
+  const int g1 = min(groups_total, g0 + gps);
+  const int col0 = G::IB * tx + G::WA;                        // first column of the aligned window (multiple of VW)
+
+  float win[NR][NW * VW];
+  auto load_row = [&](int slot, int row) {
+    // branch-free: always load from a clamped (valid) address, then zero what lies outside the image
+    // (bit mask instead of a select: hipcc turns `ok ? load : 0` back into a branch around the load, which
+    //  serialises the row's loads behind s_waitcnt)
+    const bool rok = row >= 0 && row < in_h;
+    const float* rp = src + (size_t)min(max(row, 0), in_h - 1) * in_w;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const int c = col0 + VW * q;
+      const unsigned m = (rok && c >= 0 && c + VW - 1 < in_w) ? 0xffffffffu : 0u;
+      const float* ap = rp + min(max(c, 0), in_w - VW);
+      if constexpr (VW == 4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(ap);
+        win[slot][4 * q + 0] = __uint_as_float(v.x & m);
+        win[slot][4 * q + 1] = __uint_as_float(v.y & m);
+        win[slot][4 * q + 2] = __uint_as_float(v.z & m);
+        win[slot][4 * q + 3] = __uint_as_float(v.w & m);
+      } else {
+        const uint2 v = *reinterpret_cast<const uint2*>(ap);
+        win[slot][2 * q + 0] = __uint_as_float(v.x & m);
+        win[slot][2 * q + 1] = __uint_as_float(v.y & m);
+      }
+    }
+  };
+  // window rows RF .. RL of group g0
+#pragma unroll
+  for (int r = 0; r < NR; ++r) load_row(r, g0 * ADV + G::RF + r);
+
+  for (int g = g0; g < g1; g += PH) {
+#pragma unroll
+    for (int ph = 0; ph < PH; ++ph) {
+      if (g + ph < g1) {
+        // logical window row i of this group lives in slot (i + ph*ADV) % NR
+#pragma unroll
+        for (int p = 0; p < OG; ++p) {
+          const int oy = (g + ph) * OG + p;
+          float acc[OW];
+#pragma unroll
+          for (int j = 0; j < OW; ++j) acc[j] = 0.f;
+#pragma unroll
+          for (int ky = 0; ky < K; ++ky) {
+            const int uy = p * DOWN + ky - PY0;               // compile-time after unrolling
+            if (((uy % UP) + UP) % UP != 0) continue;
+            const int ri = cfloor_div(uy, UP) - G::RF;        // logical window row
+            const int slot = (ri + ph * ADV) % NR;
+#pragma unroll
+            for (int j = 0; j < OW; ++j) {
+#pragma unroll
+              for (int kx = 0; kx < K; ++kx) {
+                const int ux = j * DOWN + kx - PX0;
+                if (((ux % UP) + UP) % UP != 0) continue;
+                const int wi = cfloor_div(ux, UP) - G::WA;     // index into the window row
+                acc[j] = fmaf(win[slot][wi], w[ky][kx], acc[j]);
+              }
+            }
+          }
+          if (oy < out_h) {
+#pragma unroll
+            for (int j4 = 0; j4 < OW / 4; ++j4) {
+              const int ox = OW * tx + 4 * j4;
+              if (ox + 3 < out_w) {
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                f4v o4 = {acc[4 * j4], acc[4 * j4 + 1], acc[4 * j4 + 2], acc[4 * j4 + 3]};
+                f4v* op = reinterpret_cast<f4v*>(dst + (size_t)oy * out_w + ox);
+                *op = o4;
+              }
+            }
+          }
+        }
+        // slide: the ADV oldest logical rows are replaced by the next group's newest rows
+        if (g + ph + 1 < g1) {
+#pragma unroll
+          for (int a = 0; a < ADV; ++a) {
+            const int slot = (a + ph * ADV) % NR;              // logical row a of this group = oldest
+            load_row(slot, (g + ph + 1) * ADV + G::RF + (NR - ADV) + a);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 struct UpfirdnParams {
   int up_x, up_y, down_x, down_y, pad_x0, pad_y0;
   int major, in_h, in_w, minor, kernel_h, kernel_w, out_h, out_w;
@@ -128,6 +282,27 @@ int launch_tiled(const float* in, const float* kernel, float* out, const Upfirdn
   dim3 grid(p.major, (p.out_h + TOH - 1) / TOH, (p.out_w + TOW - 1) / TOW);
   hipLaunchKernelGGL((upfirdn2d_tiled_kernel<UP, DOWN, K, TOH, TOW>), grid, dim3(256), 0, s, in, kernel, out,
                      p.in_h, p.in_w, p.out_h, p.out_w, p.kernel_h, p.kernel_w, p.pad_x0, p.pad_y0);
+  return ipdm_launch_status();
+}
+
+template <int UP, int DOWN, int PX0, int PY0, int OW>
+int launch_stream(const float* in, const float* kernel, float* out, const UpfirdnParams& p, hipStream_t s) {
+  using G = FirGeom<UP, DOWN, PX0, PY0, OW>;
+  const long long nq = (p.out_w + G::OW - 1) / G::OW;
+  const long long groups = (p.out_h + G::OG - 1) / G::OG;
+  // row groups per thread.  Measured on MI355X (scripts/bench_resample.py, B = 8): what a launch wants is ~2^20 vector loads
+  // in flight chip-wide -- long strips (few threads, each streaming many rows: the (NR - ADV)-row halo is amortised and the
+  // window loads of a group are all independent) until the thread count drops below that; 128 K threads for the
+  // down-sampler (8 loads per group), 350 K for the up-sampler (3).  IPDM_FIR_GPS overrides (tuning).
+  static const int tune_gps = getenv("IPDM_FIR_GPS") ? atoi(getenv("IPDM_FIR_GPS")) : 0;
+  long long gps = (long long)p.major * groups * nq * (G::ADV * G::NW) >> 20;
+  gps = gps < 1 ? 1 : (gps > 32 ? 32 : gps);
+  if (tune_gps > 0) gps = tune_gps;
+  const long long ns = (groups + gps - 1) / gps;
+  const long long threads = (long long)p.major * ns * nq;
+  if (threads >= (1LL << 31)) return IPDM_EUNSUPPORTED;         // caller falls through to the tiled kernel
+  hipLaunchKernelGGL((upfirdn2d_stream_kernel<UP, DOWN, PX0, PY0, OW>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
+                     in, kernel, out, p.major, p.in_h, p.in_w, p.out_h, p.out_w, p.kernel_h, p.kernel_w, (int)gps);
   return ipdm_launch_status();
 }
 
@@ -191,6 +366,16 @@ extern "C" int ipdm_upfirdn2d_f32(const float* in, const float* kernel, float* o
   if (major == 0) return IPDM_OK;
   hipStream_t s = ipdm_stream(stream);
   const bool sq = up_x == up_y && down_x == down_y && minor == 1 && kernel_h <= 4 && kernel_w <= 4;
+  // the NCSN++ resampling calls (models/up_or_down_sampling.py:191-257: down2 pad (1,1), up2 pad (2,1) with [1,3,3,1] taps)
+  // on float4-shaped rows -> register-streaming kernel
+  const bool vec_ok = sq && in_w % 4 == 0 && p.out_w % 4 == 0 && pad_x0 == pad_y0 &&
+                      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  int rc = IPDM_EUNSUPPORTED;
+  // (the up-sampler writes 4x what it reads: one float4 of outputs per thread and row keeps every store instruction a
+  //  contiguous KiB per wave -- 4.9 vs 3.6 TB/s at 128^2 -> 256^2 against two float4s per thread)
+  if (vec_ok && up_x == 1 && down_x == 2 && pad_x0 == 1) rc = launch_stream<1, 2, 1, 1, 4>(in, kernel, out, p, s);
+  if (vec_ok && up_x == 2 && down_x == 1 && pad_x0 == 2) rc = launch_stream<2, 1, 2, 2, 4>(in, kernel, out, p, s);
+  if (rc != IPDM_EUNSUPPORTED) return rc;
   if (sq && up_x == 1 && down_x == 2) return launch_tiled<1, 2, 4, 16, 64>(in, kernel, out, p, s);
   if (sq && up_x == 2 && down_x == 1) return launch_tiled<2, 1, 4, 32, 64>(in, kernel, out, p, s);
   if (sq && up_x == 1 && down_x == 1) return launch_tiled<1, 1, 4, 32, 64>(in, kernel, out, p, s);

@@ -96,6 +96,13 @@ def cfg5():
     t = torch.full((B,), 10.0, device=dev)
     with torch.no_grad():
         s_fwd = timed(lambda: net(x, t), n=3)
+        # the same forward replayed as one hipGraph (what a sampler that captures its score evaluation pays)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y_static = net(x, t)
+        s_graph = timed(g.replay, n=5)
+    if os.environ.get("IPDM_CFG5_FORWARD_ONLY") == "1":
+        return dict(config=5, batch=B, s_per_forward=s_fwd, s_per_forward_graph=s_graph)
     sde = sde_lib.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, cfg.model.num_scales)
     pred = sampling.get_predictor("reverse_diffusion")
     corr = sampling.get_corrector("langevin")
@@ -107,7 +114,8 @@ def cfg5():
             sampling.shared_predictor_update_fn(xc, vt, sde, net, pred, False, True)
     s_pc = timed(pc, n=2)
     n_par = sum(p.numel() for p in net.parameters())
-    return dict(config=5, batch=B, params_M=n_par / 1e6, s_per_forward=s_fwd, images_per_s_forward=B / s_fwd,
+    return dict(config=5, batch=B, params_M=n_par / 1e6, s_per_forward=s_fwd, s_per_forward_graph=s_graph,
+                images_per_s_forward=B / s_graph,
                 s_per_pc_step=s_pc, est_seconds_per_batch_2000_steps=s_pc * cfg.model.num_scales)
 
 

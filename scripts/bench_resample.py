@@ -13,13 +13,26 @@ B = int(os.environ.get("BENCH_B", 8))
 
 
 def timeit(fn, iters=20):
+    """device time per call: `iters` calls captured into one hipGraph and replayed (what a graph-replayed forward pays;
+    BENCH_EAGER=1 times eager launches instead, host launch overhead included)"""
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3
+    if os.environ.get("BENCH_EAGER") == "1":
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters * 1e-3)
+    return best
 
 
 def report(name, nbytes, t):

@@ -61,6 +61,46 @@ def test_upfirdn2d_bench_shapes(ops, shape, mode):
     np.testing.assert_allclose(y.reshape(ref.shape).cpu().numpy(), ref, atol=3e-6)
 
 
+@pytest.mark.parametrize("shape,mode,ksize,pad1", [
+    ((3, 5, 12, 20), "down", (4, 4), 1),      # width 20 -> 10 outputs would break float4 rows: tiled fallback
+    ((3, 5, 12, 24), "down", (4, 4), 1),      # 12 output columns = 3 float4 column groups
+    ((2, 7, 9, 8), "down", (4, 4), 1),        # odd height (rows beyond the image are zero padding)
+    ((2, 3, 16, 16), "down", (3, 2), 1),      # smaller tap grid, zero-extended at the high end
+    ((2, 3, 16, 16), "down", (4, 4), 3),      # larger pad1: one more output row / column of zero padding
+    ((2, 3, 16, 16), "down", (4, 4), -1),     # negative pad1 crops
+    ((3, 5, 6, 4), "up", (4, 4), 1),          # 8 output columns = exactly one column group
+    ((3, 5, 7, 12), "up", (4, 4), 1),         # 24 output columns = 3 groups, odd input height
+    ((2, 3, 8, 8), "up", (2, 3), 1),
+    ((2, 3, 8, 6), "up", (4, 4), 1),          # 12 output columns: the second float4 of the last group is outside
+    ((40, 16, 64, 64), "down", (4, 4), 1),    # long strips (several row groups per thread, ring rotation)
+    ((40, 16, 32, 32), "up", (4, 4), 1),
+])
+def test_upfirdn2d_stream_kernel(ops, shape, mode, ksize, pad1):
+    """the register-streaming FIR kernel (down2 pad0 1 / up2 pad0 2 on float4-shaped rows) and its fallbacks vs the oracle,
+    with a NON-symmetric random tap grid so that a flipped or transposed tap would show"""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(shape).astype(np.float32)
+    k = rng.standard_normal(ksize).astype(np.float32)
+    args = (1, 1, 2, 2, 1, pad1, 1, pad1) if mode == "down" else (2, 2, 1, 1, 2, pad1, 2, pad1)
+    ref = resample.upfirdn2d(x, k, *args)
+    N, C, H, W = shape
+    y = ops.upfirdn2d_raw(dev(x).reshape(N * C, H, W, 1), dev(k), *args)
+    np.testing.assert_allclose(y.reshape(ref.shape).cpu().numpy(), ref, atol=1e-5)
+    # linearity + shift structure (size-independent properties): a one-hot input reproduces the taps
+    if mode == "down" and ksize == (4, 4) and pad1 == 1 and H >= 8:
+        e = np.zeros((1, 1, H, W), np.float32)
+        e[0, 0, 4, 4] = 1.0
+        ye = ops.upfirdn2d_raw(dev(e).reshape(1, H, W, 1), dev(k), *args).reshape(H // 2, W // 2).cpu().numpy()
+        # out[oy, ox] = sum in[2oy + ky - 1, 2ox + kx - 1] * k[3 - ky, 3 - kx]  ->  taps land at oy in {1, 2}, ox in {1, 2}
+        want = np.zeros_like(ye)
+        for oy in range(H // 2):
+            for ox in range(W // 2):
+                ky, kx = 4 - 2 * oy + 1, 4 - 2 * ox + 1
+                if 0 <= ky < 4 and 0 <= kx < 4:
+                    want[oy, ox] = k[3 - ky, 3 - kx]
+        np.testing.assert_allclose(ye, want, atol=1e-7)
+
+
 def test_upfirdn2d_minor_dim(ops):
     rng = np.random.default_rng(2)
     x = rng.standard_normal((3, 9, 8, 4)).astype(np.float32)          # [major, h, w, minor]
