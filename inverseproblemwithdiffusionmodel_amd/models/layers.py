@@ -37,7 +37,7 @@ def default_init(scale=1.):
     return variance_scaling(scale, 'fan_avg', 'uniform')
 
 
-class Conv(nn.Module):
+class Conv(ops.PackedWeightMixin, nn.Module):
     """stride-1 'same' convolution with nn.Conv2d's parameter names (weight [Cout,Cin,k,k], bias)"""
 
     def __init__(self, in_planes, out_planes, kernel_size, bias=True, init_scale=1., dilation=1):
@@ -45,24 +45,18 @@ class Conv(nn.Module):
         self.in_planes, self.out_planes, self.kernel_size, self.dilation = in_planes, out_planes, kernel_size, dilation
         self.weight = nn.Parameter(default_init(init_scale)((out_planes, in_planes, kernel_size, kernel_size)))
         self.bias = nn.Parameter(torch.zeros(out_planes)) if bias else None
-        self._packed = None
+        self._cache = ops.PackedWeightCache()
 
     def packed(self):
-        v = (self.weight._version, self.weight.data_ptr())
-        if self._packed is None or self._packed[0] != v:
-            self._packed = (v, ops.conv_weight(self.weight.data))
-        return self._packed[1]
+        return self._cache.get(self.weight, "direct_" + ops.CONV_IMPL, ops.conv_weight)
 
     def packed_wino(self):
-        v = (self.weight._version, self.weight.data_ptr())
-        if getattr(self, "_wino", None) is None or self._wino[0] != v:
-            self._wino = (v, ops.conv_wino_bx3_weight(self.weight.data))
-        return self._wino[1]
+        return self._cache.get(self.weight, "wino_bx3", ops.conv_wino_bx3_weight)
 
     def forward(self, x, residual=None):
         bias = None if self.bias is None else self.bias.data
         if (ops.CONV_IMPL == "bx3" and self.kernel_size == 3
-                and ops.wino_bx3_pays(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation, x.shape[0])):
+                and ops.wino_bx3_pays(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation)):
             return ops.conv2d_wino_bx3(x, self.packed_wino(), bias, residual, dilation=self.dilation)
         return ops.conv2d(x, self.packed(), bias, residual=residual, dilation=self.dilation)
 

@@ -68,7 +68,7 @@ def conv_downsample_2d(x, w, k=None, factor=2, gain=1):
                               "or progressive*='residual', which no shipped VE config uses")
 
 
-class Conv2d(nn.Module):
+class Conv2d(ops.PackedWeightMixin, nn.Module):
     """Conv2d layer with optional FIR up/down-sampling (StyleGAN2); plain stride-1 branch implemented."""
 
     def __init__(self, in_ch, out_ch, kernel, up=False, down=False, resample_kernel=(1, 3, 3, 1), use_bias=True,
@@ -82,13 +82,12 @@ class Conv2d(nn.Module):
         if use_bias:
             self.bias = nn.Parameter(torch.zeros(out_ch))
         self.up, self.down, self.resample_kernel, self.kernel, self.use_bias = up, down, resample_kernel, kernel, use_bias
-        self._packed = None
+        self._cache = ops.PackedWeightCache()
 
     def forward(self, x):
         if self.up:
             return upsample_conv_2d(x, self.weight, k=self.resample_kernel)
         if self.down:
             return conv_downsample_2d(x, self.weight, k=self.resample_kernel)
-        if self._packed is None or self._packed[0] != self.weight._version:
-            self._packed = (self.weight._version, ops.conv_weight(self.weight.data))
-        return ops.conv2d(x, self._packed[1], self.bias.data if self.use_bias else None)
+        packed = self._cache.get(self.weight, "direct_" + ops.CONV_IMPL, ops.conv_weight)
+        return ops.conv2d(x, packed, self.bias.data if self.use_bias else None)

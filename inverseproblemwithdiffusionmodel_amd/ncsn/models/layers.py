@@ -52,7 +52,7 @@ def _act_code(act):
     raise NotImplementedError(f"no kernel code for activation {act!r}")
 
 
-class Conv2d(nn.Module):
+class Conv2d(ops.PackedWeightMixin, nn.Module):
     """stride-1 'same' convolution, kernel 1 or 3, optional dilation; weight in the reference's layout
     [Cout, Cin, k, k] (what checkpoints carry), repacked once for the selected kernel family (ops.conv_weight)."""
 
@@ -67,28 +67,19 @@ class Conv2d(nn.Module):
         nn.init.uniform_(self.weight, -bound, bound)
         if bias:
             nn.init.uniform_(self.bias, -bound, bound)
-        self._packed = None
-        self._packed_version = None
-        self._wino = None
+        self._cache = ops.PackedWeightCache()
+
+    def _cached(self, kind, build):
+        return self._cache.get(self.weight, kind, build)
 
     def packed_wino(self):
-        v = (self.weight._version, self.weight.data_ptr())
-        if self._wino is None or self._wino[0] != v:
-            self._wino = (v, ops.conv_wino_weight(self.weight.data))
-        return self._wino[1]
+        return self._cached("wino_f32", ops.conv_wino_weight)
 
     def packed_wino_bx3(self):
-        v = (self.weight._version, self.weight.data_ptr())
-        if self._wino is None or self._wino[0] != v:
-            self._wino = (v, ops.conv_wino_bx3_weight(self.weight.data))
-        return self._wino[1]
+        return self._cached("wino_bx3", ops.conv_wino_bx3_weight)
 
     def packed(self):
-        v = (self.weight._version, self.weight.data_ptr())
-        if self._packed is None or self._packed_version != v:
-            self._packed = ops.conv_weight(self.weight.data)
-            self._packed_version = v
-        return self._packed
+        return self._cached("direct_" + ops.CONV_IMPL, ops.conv_weight)
 
     def forward(self, x, coef=None, act=ops.ACT_NONE, residual=None, out=None, act_out=ops.ACT_NONE, raw=True):
         bias = None if self.bias is None else self.bias.data
@@ -99,7 +90,7 @@ class Conv2d(nn.Module):
                                    dilation=self.dilation)
         if (USE_WINOGRAD and ops.CONV_IMPL == "bx3" and self.ndim == 2 and self.kernel_size == 3 and coef is None
                 and act == ops.ACT_NONE and out is None and ops.wino_bx3_pays(self.in_planes, self.out_planes, x.shape[2],
-                                                                              x.shape[3], self.dilation, x.shape[0])):
+                                                                              x.shape[3], self.dilation)):
             return ops.conv2d_wino_bx3(x, self.packed_wino_bx3(), bias, residual, act_out=act_out, raw=raw,
                                        dilation=self.dilation)
         if self.ndim == 3:

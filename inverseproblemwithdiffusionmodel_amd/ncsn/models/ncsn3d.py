@@ -12,7 +12,7 @@ from .layers3d import ResidualBlock, RefineBlock, Conv3d
 from ... import ops
 
 
-class _TemporalConv(nn.Module):
+class _TemporalConv(ops.PackedWeightMixin, nn.Module):
     """nn.Conv3d / nn.ConvTranspose3d with kernel (1,1,4), stride (1,1,2), padding (0,0,1): parameter names and
     shapes of the torch modules ([Cout,Cin,1,1,4] resp. [Cin,Cout,1,1,4]); executed as gather + 1x1 conv."""
 
@@ -25,16 +25,16 @@ class _TemporalConv(nn.Module):
         bound = 1.0 / ((out_ch if transposed else in_ch) * 4) ** 0.5
         nn.init.uniform_(self.weight, -bound, bound)
         nn.init.uniform_(self.bias, -bound, bound)
-        self._packed = None
+        self._cache = ops.PackedWeightCache()
+
+    def _pack(self, weight):
+        w = weight[:, :, 0, 0, :]                                            # [a, b, 4]
+        # gathered channel index = ci*4 + k : an ordinary 1x1 kernel [Cout][4*Cin][1][1]
+        w1 = (w.permute(1, 0, 2) if self.transposed else w).reshape(self.out_ch, self.in_ch * 4, 1, 1)
+        return ops.conv_weight(w1.contiguous())
 
     def packed(self):
-        v = (self.weight._version, self.weight.data_ptr())
-        if self._packed is None or self._packed[0] != v:
-            w = self.weight.data[:, :, 0, 0, :]                              # [a, b, 4]
-            # gathered channel index = ci*4 + k : an ordinary 1x1 kernel [Cout][4*Cin][1][1]
-            w1 = (w.permute(1, 0, 2) if self.transposed else w).reshape(self.out_ch, self.in_ch * 4, 1, 1)
-            self._packed = (v, ops.conv_weight(w1.contiguous()))
-        return self._packed[1]
+        return self._cache.get(self.weight, "taps_" + ops.CONV_IMPL, self._pack)
 
     def forward(self, x):
         B, C, D, H, T = x.shape

@@ -499,6 +499,38 @@ if CONV_IMPL not in ("bx3", "f32"):
     raise ValueError(f"IPDM_CONV_IMPL={CONV_IMPL!r}: expected 'bx3' or 'f32'")
 
 
+class PackedWeightCache:
+    """Packed copies of ONE parameter, one entry per (kernel family, layout), each tagged with the parameter's
+    (version counter, storage pointer, device).  In-place optimiser steps and `copy_` on the parameter bump the version;
+    a write through `.data` (the reference's EMA swap, helpers/utils.py:161-170) does not: modules clear the cache in
+    their load_state_dict hook, and anything else that writes `.data` must call the module's invalidate()."""
+
+    def __init__(self):
+        self._entries = {}
+
+    def clear(self):
+        self._entries.clear()
+
+    def get(self, weight, kind, build):
+        tag = (weight._version, weight.data_ptr(), str(weight.device))
+        hit = self._entries.get(kind)
+        if hit is None or hit[0] != tag:
+            hit = (tag, build(weight.data))
+            self._entries[kind] = hit
+        return hit[1]
+
+
+class PackedWeightMixin:
+    """for conv modules holding `self.weight`: `self._cache` + invalidate() + the load_state_dict hook"""
+
+    def invalidate(self):
+        self._cache.clear()
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._cache.clear()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+
 def conv_weight(w):
     """pack a convolution weight for the selected kernel family; pass the result to conv2d / conv3d"""
     return conv_bx3_weight(w) if CONV_IMPL == "bx3" else conv_pack_weight(w)
@@ -602,8 +634,12 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
     if CONV_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("ipdm_conv2d_wino_bx3_f32", _ptr(x), _ptr(U.blob), _ptr(bias), _ptr(residual), _ptr(out), _ptr(out_act), act_out,
-         B, Cin, Cout, H, W, dilation, _stream())
+    nb = wino_bx3_max_batch(Cin, H, W, dilation)
+    for b0 in range(0, B, nb):           # one launch unless the batch outgrows the kernel's 32-bit buffer offsets
+        b1 = min(B, b0 + nb)
+        call("ipdm_conv2d_wino_bx3_f32", _ptr(x[b0:b1]), _ptr(U.blob), _ptr(bias),
+             _ptr(None if residual is None else residual[b0:b1]), _ptr(None if out is None else out[b0:b1]),
+             _ptr(None if out_act is None else out_act[b0:b1]), act_out, b1 - b0, Cin, Cout, H, W, dilation, _stream())
     if CONV_TRACE is not None:
         e1.record()
         CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, res=residual is not None,
@@ -611,18 +647,23 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
     return (out, out_act) if want_act else out
 
 
-def wino_bx3_pays(Cin, Cout, H, W, dilation=1, B=1):
+def wino_bx3_pays(Cin, Cout, H, W, dilation=1, B=None):
     """dispatch rule measured on MI355X (scripts/bench_conv.py): the split-bf16 Winograd kernel beats the direct
-    split-bf16 kernel wherever it is eligible, except on undilated images of 16 pixels or less across (a single
-    64-tile workgroup per image and channel tile leaves most of the chip idle)"""
+    split-bf16 kernel wherever it is eligible, except on undilated images of 16 pixels or less with fewer than 512
+    output channels (one 8x8-tile workgroup per (image, channel tile): at the production batch only the 512-channel
+    layers fill the chip; with 256 channels the direct kernel's finer tiles tie).
+    The rule depends on the LAYER SHAPE ONLY -- never on the batch -- so that a sample's bits do not depend on how many
+    other samples share its GPU (sharding.py's invariance; `B` is accepted and ignored for old call sites)."""
     if W <= 16 and dilation == 1:
-        # one 8x8-tile workgroup per (image, channel tile): pays once those pairs fill the chip (512 -> 512 at B = 28:
-        # 224 pairs); with fewer the direct kernel's finer tiles win
-        if H > 16 or B * (Cout // 64) < 160 or Cin < 32:
+        if H > 16 or Cout < 512 or Cin < 32:
             return False
-    if B * Cin * H * W * 4 >= (0x1fffffff if (W < 32 or dilation > 1) else 0x3fffffff):   # buffer-descriptor reach
-        return False
     return conv_wino_bx3_supported(Cin, Cout, H, W, dilation)
+
+
+def wino_bx3_max_batch(Cin, H, W, dilation=1):
+    """images per launch the Winograd kernel's 32-bit buffer offsets reach (larger batches run as several launches)"""
+    reach = 0x1fffffff if (W < 32 or dilation > 1) else 0x3fffffff
+    return max(1, (reach - 1) // (Cin * H * W * 4))
 
 
 def adam_ascent(x, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8):

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$ROOT/profiles"
 cd "$ROOT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o "$TAG" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-alt > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o "$TAG" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-alt --no-full-batch > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
 STATS=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
 echo "stats file: $STATS"
 head -40 "$STATS" > "$ROOT/profiles/${TAG}_kernel_stats.csv"

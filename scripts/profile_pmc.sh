@@ -11,7 +11,7 @@ cd "$ROOT"
 for C in FETCH_SIZE WRITE_SIZE; do
   OUT=$ROOT/gpurun_out/pmc_${TAG}_$C
   rm -rf "$OUT"; mkdir -p "$OUT"
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT" -o pmc -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-graph > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT" -o pmc -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-full-batch --no-graph > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
   echo "pass $C done: $(find "$OUT" -name '*counter_collection.csv' | head -1)"
 done
 python3 - "$TAG" <<'PY'

@@ -117,16 +117,40 @@ def test_full_size_ncsnv2_deepest(pkg, golden):
     impl = ops.CONV_IMPL
     try:
         ops.CONV_IMPL = "f32" if impl == "bx3" else "bx3"
-        for m in net.modules():
-            if hasattr(m, "_packed"):
-                m._packed, m._wino = None, None
-                if hasattr(m, "_packed_version"):
-                    m._packed_version = None
         y_other = net(xg, lg).cpu().numpy()
     finally:
         ops.CONV_IMPL = impl
     assert metrics.nrmse(y_other, y) < 2e-5
     assert np.abs(y_other - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
+def test_packed_weight_cache_invalidation(pkg):
+    """packed / Winograd-domain weight caches.  Entries are per (kernel family, layout), so toggling
+    ops.CONV_IMPL can never return a blob of the other family; load_state_dict() and in-place (`copy_`) updates refresh
+    them; a raw `.data` write (the reference's EMA swap) needs invalidate()."""
+    from inverseproblemwithdiffusionmodel_amd import ops
+    conv = pkg.layers.Conv2d(64, 64, 3).cuda()
+    x = torch.randn(2, 64, 32, 32, device="cuda")
+    ref = lambda: torch.nn.functional.conv2d(x.double(), conv.weight.data.double(), conv.bias.data.double(), padding=1)
+    close = lambda y: float((y.double() - ref()).abs().max()) < 2e-5 * max(1.0, float(ref().abs().max()))
+    assert close(conv(x))
+    impl = ops.CONV_IMPL
+    try:
+        ops.CONV_IMPL = "f32" if impl == "bx3" else "bx3"          # other family: its own cache entry
+        assert close(conv(x))
+    finally:
+        ops.CONV_IMPL = impl
+    assert close(conv(x))
+    with torch.no_grad():
+        conv.weight.mul_(-0.5)                                      # in-place on the parameter: version bump
+    assert close(conv(x))
+    sd = {k: v.clone() * 3.0 for k, v in conv.state_dict().items()}
+    conv.load_state_dict(sd)                                        # hook clears the cache
+    assert close(conv(x))
+    conv.weight.data.copy_(torch.randn_like(conv.weight.data) * 0.05)   # EMA-style write through .data: not seen ...
+    stale = conv(x)
+    conv.invalidate()                                                # ... until invalidated
+    assert close(conv(x)) and not close(stale)
 
 
 class _Tape:
@@ -381,11 +405,6 @@ def test_full_size_trajectory_bf16x3_vs_fp32_mfma():
         old = ops.CONV_IMPL
         try:
             ops.CONV_IMPL = impl
-            for m in prob.scorenet.modules():
-                if hasattr(m, "_packed"):
-                    m._packed, m._wino = None, None
-                    if hasattr(m, "_packed_version"):
-                        m._packed_version = None
             return prob.sampler(**kw)[0].numpy()
         finally:
             ops.CONV_IMPL = old
