@@ -35,7 +35,7 @@ extern "C" {
 #define IPDM_ACT_SWISH 4
 
 /* library identification: returns IPDM_ABI_VERSION, writes the gfx arch string the kernels were built for */
-#define IPDM_ABI_VERSION 1
+#define IPDM_ABI_VERSION 2
 int ipdm_abi_version(void);
 const char* ipdm_build_arch(void);
 
@@ -82,11 +82,18 @@ int64_t ipdm_fft2c_workspace_bytes(int batch, int H, int W);
  *  undersampling_fourier.py:77-82) */
 int ipdm_sense_forward_c64(const float* x, const float* sens, const uint8_t* mask, int mask_t,
                            float* y, int B, int n_coils, int H, int W, void* stream);
-/* x[b] = sum_c S_c * ifft2c(mask? mask*s : s)    apply_mask == 0 reproduces SENSE.conj_op */
+/* Scratch the SENSE / single-coil operators below need for (B, n_coils, H, W):
+ *   power-of-two images up to 128x128 (one kernel, image resident in LDS): B*H*W*8 bytes for the proximal operators'
+ *   coil sum, nothing for forward / adjoint / SSOS;
+ *   larger power-of-two images (e.g. the reference's 256x256 ACDC slices, helpers/load_data.py:274; row / column FFT
+ *   passes): n_coils*B*H*W*8 bytes for every operator except ipdm_sense_forward_c64 (single-coil: n_coils = 1). */
+int64_t ipdm_sense_workspace_bytes(int B, int n_coils, int H, int W);
+/* x[b] = sum_c S_c * ifft2c(mask? mask*s : s)    apply_mask == 0 reproduces SENSE.conj_op; workspace: see above
+ * (may be NULL up to 128x128) */
 int ipdm_sense_adjoint_c64(const float* s, const float* sens, const uint8_t* mask, int mask_t,
-                           int apply_mask, float* x, int B, int n_coils, int H, int W, void* stream);
+                           int apply_mask, float* x, float* workspace, int B, int n_coils, int H, int W, void* stream);
 /* out[b] = sqrt(sum_c |ifft2c(s[c][b])|^2)    float32 [B][H][W] */
-int ipdm_sense_ssos_c64(const float* s, float* out, int B, int n_coils, int H, int W, void* stream);
+int ipdm_sense_ssos_c64(const float* s, float* out, float* workspace, int B, int n_coils, int H, int W, void* stream);
 
 /* L2Penalty with a SENSE operator, closed form of its one SGD step:
  *   x = z - coef * A^H(A z - y),   coef = 0.05 * (alpha/lamda) / (n_coils * W)  (computed by the caller)
@@ -94,7 +101,8 @@ int ipdm_sense_ssos_c64(const float* s, float* out, int B, int n_coils, int H, i
  * written planar to out_re / out_im (may alias z_re / z_im). */
 int ipdm_sense_l2prox_f32(const float* z_re, const float* z_im, const float* y, const float* sens,
                           const uint8_t* mask, int mask_t, float coef, float* out_re, float* out_im,
-                          float* work /* [B][H][W] c64 scratch */, int B, int n_coils, int H, int W, void* stream);
+                          float* work /* ipdm_sense_workspace_bytes(B, n_coils, H, W) */, int B, int n_coils, int H, int W,
+                          void* stream);
 
 /* Per-iteration scalars held in DEVICE memory, so that a captured hipGraph of one iteration can be
  * replayed for every noise level without re-instantiation: the host (or a tiny kernel) rewrites the
@@ -117,7 +125,8 @@ int ipdm_ald_sense_step_f32(float* x_re, float* x_im, const float* g_re, const f
                             float step, float noise_scale, uint64_t seed, int64_t sample_offset, int64_t step_id,
                             const ipdm_sched_t* dev_sched /* device; non-NULL overrides step/noise_scale/coef/step_id */,
                             const float* y, const float* sens, const uint8_t* mask, int mask_t, float coef,
-                            float* work /* [B][H][W] c64 scratch */, int B, int n_coils, int H, int W, void* stream);
+                            float* work /* ipdm_sense_workspace_bytes(B, n_coils, H, W) */, int B, int n_coils, int H, int W,
+                            void* stream);
 
 /* Single-coil data-consistency operators (A = M F, RandomUndersamplingFourier, no coil maps) on planar real/imag
  * float32 [B][H][W], y [B][H][W] complex64; out may alias z.  mode:
@@ -127,7 +136,9 @@ int ipdm_ald_sense_step_f32(float* x_re, float* x_im, const float* g_re, const f
  *   2  RandomUndersamplingFourier.projection (undersampling_fourier.py:89-97) = Constrained.__call__ (proximal_op.py:62-69):
  *      x = F^-1[coef*y + (1-coef) M F z + (1-M) F z], coef = lamda */
 int ipdm_singlecoil_prox_f32(const float* z_re, const float* z_im, const float* y, const uint8_t* mask, int mask_t,
-                             float coef, int mode, float* out_re, float* out_im, int B, int H, int W, void* stream);
+                             float coef, int mode, float* out_re, float* out_im,
+                             float* workspace /* ipdm_sense_workspace_bytes(B, 1, H, W); NULL allowed up to 128x128 */,
+                             int B, int H, int W, void* stream);
 
 /* One fused Annealed-Langevin iteration tail for the single-coil samplers (the reference's
  * scripts/acdc_inv_seg_sampling_keep_center_prox_real_imag.py:79-89 and cine_inv_sampling_keep_center_prox_real_imag.py:78-88
@@ -137,7 +148,8 @@ int ipdm_ald_singlecoil_step_f32(float* x_re, float* x_im, const float* g_re, co
                                  const float* noise_re, const float* noise_im,
                                  float step, float noise_scale, uint64_t seed, int64_t sample_offset, int64_t step_id,
                                  const ipdm_sched_t* dev_sched, const float* y, const uint8_t* mask, int mask_t,
-                                 float coef, int mode, int B, int H, int W, void* stream);
+                                 float coef, int mode, float* workspace /* as ipdm_singlecoil_prox_f32 */, int B, int H,
+                                 int W, void* stream);
 
 /* Langevin update alone (ALD_optimizers.py:117): x += step*g + noise_scale*noise ; noise NULL -> Philox. */
 int ipdm_langevin_step_f32(float* x, const float* g, const float* noise, float step, float noise_scale,

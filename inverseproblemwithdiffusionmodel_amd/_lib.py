@@ -27,14 +27,15 @@ SIGNATURES = {
     "ipdm_fft2c_c64": [P, P, c_int, c_int, c_int, c_int, P, P],
     "ipdm_fft2c_workspace_bytes": [c_int, c_int, c_int],
     "ipdm_sense_forward_c64": [P, P, P, c_int, P, c_int, c_int, c_int, c_int, P],
-    "ipdm_sense_adjoint_c64": [P, P, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P],
-    "ipdm_sense_ssos_c64": [P, P, c_int, c_int, c_int, c_int, P],
+    "ipdm_sense_workspace_bytes": [c_int, c_int, c_int, c_int],
+    "ipdm_sense_adjoint_c64": [P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_int, P],
+    "ipdm_sense_ssos_c64": [P, P, P, c_int, c_int, c_int, c_int, P],
     "ipdm_sense_l2prox_f32": [P, P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_int, c_int, P],
     "ipdm_ald_sense_step_f32": [P, P, P, P, P, P, c_float, c_float, c_uint64, c_int64, c_int64, P,
                                 P, P, P, c_int, c_float, P, c_int, c_int, c_int, c_int, P],
-    "ipdm_singlecoil_prox_f32": [P, P, P, P, c_int, c_float, c_int, P, P, c_int, c_int, c_int, P],
+    "ipdm_singlecoil_prox_f32": [P, P, P, P, c_int, c_float, c_int, P, P, P, c_int, c_int, c_int, P],
     "ipdm_ald_singlecoil_step_f32": [P, P, P, P, P, P, c_float, c_float, c_uint64, c_int64, c_int64, P,
-                                     P, P, c_int, c_float, c_int, c_int, c_int, c_int, P],
+                                     P, P, c_int, c_float, c_int, P, c_int, c_int, c_int, P],
     "ipdm_langevin_step_f32": [P, P, P, c_float, c_float, c_uint64, c_int64, c_int64, P, c_int64, c_int64, P],
     "ipdm_philox_normal_f32": [P, c_uint64, c_int64, c_int64, c_int, c_int64, c_int64, P],
     "ipdm_philox_block_host": [c_uint64, c_int64, c_int64, c_int, ctypes.c_uint32, P],
@@ -74,7 +75,7 @@ SIGNATURES = {
     "ipdm_conv2d_wino_bx3_supported": [c_int, c_int, c_int, c_int, c_int],
     "ipdm_conv2d_wino_bx3_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
 }
-_RESTYPES = {"ipdm_build_arch": c_char_p, "ipdm_fft2c_workspace_bytes": c_int64, "ipdm_conv_bx3_weight_bytes": c_int64,
+_RESTYPES = {"ipdm_build_arch": c_char_p, "ipdm_fft2c_workspace_bytes": c_int64, "ipdm_sense_workspace_bytes": c_int64, "ipdm_conv_bx3_weight_bytes": c_int64,
              "ipdm_conv_wino_bx3_weight_bytes": c_int64}
 
 IPDM_EINVAL = -1

@@ -8,117 +8,11 @@
 // The fftshift/ifftshift pairs of i2k_complex / k2i_complex (ncsn/linear_transforms/__init__.py:36-57)
 // are folded into (-1)^(r+c) sign flips before and after an ordinary FFT (exact for sizes % 4 == 0);
 // sizes the LDS path cannot take go through a direct centred DFT with an exact integer phase index.
-#include "ipdm_common.h"
+#include "kspace_fft.h"
 
 namespace {
 
-constexpr int FFT_THREADS = 1024;
-constexpr int FFT_MAX_ELEMS = 16384;           // 128 KiB of float2
-constexpr int FFT_EPT = FFT_MAX_ELEMS / FFT_THREADS;
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-
-// LDS image + twiddle table.  tw[q] = exp(-2*pi*i*q/twN), twN = max(H, W).
-struct FftLds {
-  float2* buf;
-  float2* tw;
-  int twN;
-};
-
-__device__ __forceinline__ void fft_make_twiddles(const FftLds& L) {
-  for (int q = threadIdx.x; q < L.twN; q += blockDim.x) {
-    double s, c;
-    sincospi(-2.0 * (double)q / (double)L.twN, &s, &c);
-    L.tw[q] = make_float2((float)c, (float)s);
-  }
-}
-
-// One in-place Stockham stage of radix R over `nlines` lines of length N.
-//   element (line, n) lives at buf[line*ls + n*es];  lines_fast: consecutive threads -> consecutive lines.
-// Every thread reads all its butterflies, the workgroup barriers, then everyone writes.
-template <int R>
-__device__ __forceinline__ void fft_stage(const FftLds& L, int N, int Ns, int es, int ls, int nlines, bool lines_fast,
-                                          bool inverse) {
-  constexpr int BPT = FFT_EPT / R;             // butterflies per thread at the largest image
-  const int nb = N / R;                        // butterflies per line
-  const int total = nb * nlines;
-  const int twstep = L.twN / (Ns * R);
-  float2 v[BPT][R];
-  int dst[BPT];
-#pragma unroll
-  for (int u = 0; u < BPT; ++u) {
-    int i = threadIdx.x + u * FFT_THREADS;
-    dst[u] = -1;
-    if (i < total) {
-      int line, j;
-      if (lines_fast) { j = i / nlines; line = i - j * nlines; }
-      else { line = i / nb; j = i - line * nb; }
-      int k = j & (Ns - 1);
-      int base = line * ls;
-#pragma unroll
-      for (int t = 0; t < R; ++t) {
-        float2 x = L.buf[base + (j + t * nb) * es];
-        if (t > 0) {
-          float2 w = L.tw[(k * t * twstep) & (L.twN - 1)];
-          if (inverse) w.y = -w.y;
-          x = cmul(x, w);
-        }
-        v[u][t] = x;
-      }
-      dst[u] = base + (((j - k) * R) + k) * es;
-      if constexpr (R == 2) {
-        float2 a = v[u][0], b = v[u][1];
-        v[u][0] = make_float2(a.x + b.x, a.y + b.y);
-        v[u][1] = make_float2(a.x - b.x, a.y - b.y);
-      } else {
-        float2 a = v[u][0], b = v[u][1], c = v[u][2], d = v[u][3];
-        float2 apc = make_float2(a.x + c.x, a.y + c.y), amc = make_float2(a.x - c.x, a.y - c.y);
-        float2 bpd = make_float2(b.x + d.x, b.y + d.y), bmd = make_float2(b.x - d.x, b.y - d.y);
-        // forward: -i*(b-d) = (bmd.y, -bmd.x); inverse: +i*(b-d) = (-bmd.y, bmd.x)
-        float2 jb = inverse ? make_float2(-bmd.y, bmd.x) : make_float2(bmd.y, -bmd.x);
-        v[u][0] = make_float2(apc.x + bpd.x, apc.y + bpd.y);
-        v[u][1] = make_float2(amc.x + jb.x, amc.y + jb.y);
-        v[u][2] = make_float2(apc.x - bpd.x, apc.y - bpd.y);
-        v[u][3] = make_float2(amc.x - jb.x, amc.y - jb.y);
-      }
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < BPT; ++u) {
-    if (dst[u] >= 0) {
-#pragma unroll
-      for (int t = 0; t < R; ++t) L.buf[dst[u] + t * Ns * es] = v[u][t];
-    }
-  }
-  __syncthreads();
-}
-
-__device__ __forceinline__ void fft_lines(const FftLds& L, int N, int es, int ls, int nlines, bool lines_fast,
-                                          bool inverse) {
-  int Ns = 1;
-  while (Ns * 4 <= N) {
-    fft_stage<4>(L, N, Ns, es, ls, nlines, lines_fast, inverse);
-    Ns *= 4;
-  }
-  if (Ns < N) fft_stage<2>(L, N, Ns, es, ls, nlines, lines_fast, inverse);
-}
-
-// plain (uncentred, unnormalised) 2-D FFT of buf[H][W]; caller applies the (-1)^(r+c) flips and 1/sqrt(HW).
-__device__ __forceinline__ void fft2_lds(const FftLds& L, int H, int W, bool inverse) {
-  fft_lines(L, W, 1, W, H, false, inverse);   // along rows
-  fft_lines(L, H, W, 1, W, true, inverse);    // along columns
-}
-
-__device__ __forceinline__ float sign_rc(int r, int c) { return ((r + c) & 1) ? -1.f : 1.f; }
-
-__host__ __device__ __forceinline__ bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
-static inline bool lds_fft_ok(int H, int W) {
-  return is_pow2(H) && is_pow2(W) && H >= 4 && W >= 4 && (int64_t)H * W <= FFT_MAX_ELEMS;
-}
-static inline size_t lds_bytes(int H, int W) { return ((size_t)H * W + (size_t)(H > W ? H : W)) * sizeof(float2); }
+using namespace ipdm_kspace;
 
 #define FFT_LDS_SETUP(H, W)                                   \
   extern __shared__ __align__(16) unsigned char smem_raw[];  \
@@ -186,9 +80,6 @@ __global__ __launch_bounds__(256) void dft_rows_transposed_kernel(const float2* 
 }
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool mask_at(const uint8_t* mask, int mask_t, int b, int W, int c) {
-  return mask[(size_t)(mask_t == 1 ? 0 : b % mask_t) * W + c] != 0;
-}
 
 __global__ __launch_bounds__(FFT_THREADS) void sense_forward_kernel(const float2* __restrict__ x,
                                                                     const float* __restrict__ sens,
@@ -462,7 +353,13 @@ static int set_lds_limit(K kernel, size_t bytes) {
 
 extern "C" int64_t ipdm_fft2c_workspace_bytes(int batch, int H, int W) {
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
-  return lds_fft_ok(H, W) ? 0 : (int64_t)batch * H * W * 8;
+  return (lds_fft_ok(H, W) || ipdm_kspace_large::large_ok(H, W)) ? 0 : (int64_t)batch * H * W * 8;
+}
+
+extern "C" int64_t ipdm_sense_workspace_bytes(int B, int n_coils, int H, int W) {
+  if (B <= 0 || n_coils <= 0 || H <= 0 || W <= 0) return 0;
+  if (lds_fft_ok(H, W)) return (int64_t)B * H * W * 8;        // coil-sum scratch of the single-kernel path
+  return ipdm_kspace_large::workspace_bytes(B, n_coils, H, W);
 }
 
 extern "C" int ipdm_fft2c_c64(const float* in, float* out, int batch, int H, int W, int inverse, float* workspace,
@@ -479,6 +376,9 @@ extern "C" int ipdm_fft2c_c64(const float* in, float* out, int batch, int H, int
                        reinterpret_cast<float2*>(out), H, W, inverse);
     return ipdm_launch_status();
   }
+  if (ipdm_kspace_large::large_ok(H, W))
+    return ipdm_kspace_large::fft2c(reinterpret_cast<const float2*>(in), reinterpret_cast<float2*>(out), batch, H, W,
+                                    inverse, s);
   IPDM_REQUIRE(workspace);
   // pass 1: DFT along W, [b][H][W] -> ws [b][W][H]; pass 2: DFT along H, ws -> out [b][H][W]
   hipLaunchKernelGGL(dft_rows_transposed_kernel, dim3(H, batch), dim3(256), (size_t)2 * W * sizeof(float2), s,
@@ -493,6 +393,9 @@ extern "C" int ipdm_sense_forward_c64(const float* x, const float* sens, const u
   IPDM_REQUIRE(B >= 0 && n_coils > 0 && H > 0 && W > 0 && mask_t > 0);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && mask && y && (sens || n_coils == 1));
+  if (ipdm_kspace_large::large_ok(H, W))
+    return ipdm_kspace_large::sense_forward(reinterpret_cast<const float2*>(x), sens, mask, mask_t,
+                                            reinterpret_cast<float2*>(y), B, n_coils, H, W, ipdm_stream(stream));
   if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
   size_t lds = lds_bytes(H, W);
   int rc = set_lds_limit(sense_forward_kernel, lds);
@@ -503,11 +406,18 @@ extern "C" int ipdm_sense_forward_c64(const float* x, const float* sens, const u
 }
 
 extern "C" int ipdm_sense_adjoint_c64(const float* s, const float* sens, const uint8_t* mask, int mask_t,
-                                      int apply_mask, float* x, int B, int n_coils, int H, int W, void* stream) {
+                                      int apply_mask, float* x, float* workspace, int B, int n_coils, int H, int W,
+                                      void* stream) {
   IPDM_REQUIRE(B >= 0 && n_coils > 0 && H > 0 && W > 0);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(s && sens && x);
   if (apply_mask) IPDM_REQUIRE(mask && mask_t > 0);
+  if (ipdm_kspace_large::large_ok(H, W)) {
+    IPDM_REQUIRE(workspace);
+    return ipdm_kspace_large::sense_adjoint(reinterpret_cast<const float2*>(s), sens, mask, mask_t > 0 ? mask_t : 1,
+                                            apply_mask, reinterpret_cast<float2*>(x), nullptr,
+                                            reinterpret_cast<float2*>(workspace), B, n_coils, H, W, ipdm_stream(stream));
+  }
   if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
   size_t lds = lds_bytes(H, W);
   int rc = set_lds_limit(sense_adjoint_kernel<false>, lds);
@@ -518,10 +428,16 @@ extern "C" int ipdm_sense_adjoint_c64(const float* s, const float* sens, const u
   return ipdm_launch_status();
 }
 
-extern "C" int ipdm_sense_ssos_c64(const float* s, float* out, int B, int n_coils, int H, int W, void* stream) {
+extern "C" int ipdm_sense_ssos_c64(const float* s, float* out, float* workspace, int B, int n_coils, int H, int W,
+                                   void* stream) {
   IPDM_REQUIRE(B >= 0 && n_coils > 0 && H > 0 && W > 0);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(s && out);
+  if (ipdm_kspace_large::large_ok(H, W)) {
+    IPDM_REQUIRE(workspace);
+    return ipdm_kspace_large::sense_adjoint(reinterpret_cast<const float2*>(s), nullptr, nullptr, 1, 0, nullptr, out,
+                                            reinterpret_cast<float2*>(workspace), B, n_coils, H, W, ipdm_stream(stream));
+  }
   if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
   size_t lds = lds_bytes(H, W);
   int rc = set_lds_limit(sense_adjoint_kernel<true>, lds);
@@ -537,11 +453,16 @@ extern "C" int ipdm_sense_l2prox_f32(const float* z_re, const float* z_im, const
   IPDM_REQUIRE(B >= 0 && n_coils > 0 && H > 0 && W > 0 && mask_t > 0);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(z_re && z_im && y && sens && mask && out_re && out_im && work);
-  if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
+  const bool large = ipdm_kspace_large::large_ok(H, W);
+  if (!large && !lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
   hipStream_t st = ipdm_stream(stream);
   const size_t bytes = (size_t)B * H * W * sizeof(float);
   if (out_re != z_re && hipMemcpyAsync(out_re, z_re, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
   if (out_im != z_im && hipMemcpyAsync(out_im, z_im, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
+  if (large)
+    return ipdm_kspace_large::prox_step(out_re, out_im, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0ull, 0, 0, nullptr,
+                                        reinterpret_cast<const float2*>(y), sens, mask, mask_t, coef, 0,
+                                        reinterpret_cast<float2*>(work), B, n_coils, H, W, st);
   size_t lds = lds_bytes(H, W);
   int rc = set_lds_limit(ald_sense_step_kernel<false>, lds);
   if (rc) return rc;
@@ -560,6 +481,10 @@ extern "C" int ipdm_ald_sense_step_f32(float* x_re, float* x_im, const float* g_
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x_re && x_im && g_re && g_im && y && sens && mask && work);
   IPDM_REQUIRE((noise_re == nullptr) == (noise_im == nullptr));
+  if (ipdm_kspace_large::large_ok(H, W))
+    return ipdm_kspace_large::prox_step(x_re, x_im, g_re, g_im, noise_re, noise_im, step, noise_scale, seed, sample_offset,
+                                        step_id, dev_sched, reinterpret_cast<const float2*>(y), sens, mask, mask_t, coef, 0,
+                                        reinterpret_cast<float2*>(work), B, n_coils, H, W, ipdm_stream(stream));
   if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
   size_t lds = lds_bytes(H, W);
   int rc = set_lds_limit(ald_sense_step_kernel<true>, lds);
@@ -572,16 +497,23 @@ extern "C" int ipdm_ald_sense_step_f32(float* x_re, float* x_im, const float* g_
 }
 
 extern "C" int ipdm_singlecoil_prox_f32(const float* z_re, const float* z_im, const float* y, const uint8_t* mask,
-                                        int mask_t, float coef, int mode, float* out_re, float* out_im, int B, int H,
-                                        int W, void* stream) {
+                                        int mask_t, float coef, int mode, float* out_re, float* out_im, float* workspace,
+                                        int B, int H, int W, void* stream) {
   IPDM_REQUIRE(B >= 0 && H > 0 && W > 0 && mask_t > 0 && mode >= 0 && mode <= 2);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(z_re && z_im && y && mask && out_re && out_im);
-  if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
+  const bool large = ipdm_kspace_large::large_ok(H, W);
+  if (!large && !lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
   hipStream_t st = ipdm_stream(stream);
   const size_t bytes = (size_t)B * H * W * sizeof(float);
   if (out_re != z_re && hipMemcpyAsync(out_re, z_re, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
   if (out_im != z_im && hipMemcpyAsync(out_im, z_im, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
+  if (large) {
+    IPDM_REQUIRE(workspace);
+    return ipdm_kspace_large::prox_step(out_re, out_im, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0ull, 0, 0, nullptr,
+                                        reinterpret_cast<const float2*>(y), nullptr, mask, mask_t, coef, mode,
+                                        reinterpret_cast<float2*>(workspace), B, 1, H, W, st);
+  }
   size_t lds = lds_bytes(H, W);
   int rc = set_lds_limit(ald_singlecoil_step_kernel<false>, lds);
   if (rc) return rc;
@@ -595,11 +527,17 @@ extern "C" int ipdm_ald_singlecoil_step_f32(float* x_re, float* x_im, const floa
                                             const float* noise_re, const float* noise_im, float step, float noise_scale,
                                             uint64_t seed, int64_t sample_offset, int64_t step_id,
                                             const ipdm_sched_t* dev_sched, const float* y, const uint8_t* mask, int mask_t,
-                                            float coef, int mode, int B, int H, int W, void* stream) {
+                                            float coef, int mode, float* workspace, int B, int H, int W, void* stream) {
   IPDM_REQUIRE(B >= 0 && H > 0 && W > 0 && mask_t > 0 && mode >= 0 && mode <= 2);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x_re && x_im && g_re && g_im && y && mask);
   IPDM_REQUIRE((noise_re == nullptr) == (noise_im == nullptr));
+  if (ipdm_kspace_large::large_ok(H, W)) {
+    IPDM_REQUIRE(workspace);
+    return ipdm_kspace_large::prox_step(x_re, x_im, g_re, g_im, noise_re, noise_im, step, noise_scale, seed, sample_offset,
+                                        step_id, dev_sched, reinterpret_cast<const float2*>(y), nullptr, mask, mask_t, coef,
+                                        mode, reinterpret_cast<float2*>(workspace), B, 1, H, W, ipdm_stream(stream));
+  }
   if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
   size_t lds = lds_bytes(H, W);
   int rc = set_lds_limit(ald_singlecoil_step_kernel<true>, lds);

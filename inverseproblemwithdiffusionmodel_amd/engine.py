@@ -9,6 +9,8 @@ from argparse import Namespace
 import numpy as np
 import torch
 
+from . import ops as ops_mod
+
 from .helpers.load_data import load_config
 from .ncsn.linear_transforms.undersampling_fourier import SENSE
 from .ncsn.models import get_sigmas
@@ -95,7 +97,7 @@ class IterationRunner:
         self.table_dev = torch.from_numpy(table.view(np.uint8).reshape(L * n_each, -1).copy()).to(dev)
         self.label_table = torch.arange(L, device=dev)[:, None].repeat(1, 2 * B)
         self.st = dict(x=self.x, B=B, y=meas, sc_mode=None, sens=s.linear_tfm.sens_f32(dev), mask=s.linear_tfm.mask_u8(dev),
-                       work=torch.empty(B * H * W * 2, dtype=torch.float32, device=dev),
+                       work=ops_mod.sense_workspace(B, s.linear_tfm.sens_maps.shape[0], H, W, dev),
                        labels=torch.zeros(2 * B, dtype=torch.long, device=dev), noise_re=None, noise_im=None,
                        seed=seed, sample_offset=sample_offset,
                        sched_dev=torch.zeros(SCHED_DTYPE.itemsize, dtype=torch.uint8, device=dev))

@@ -169,7 +169,7 @@ class ALDInvSegProximalRealImag(ALDOptimizer):
         else:                                # single-coil RandomUndersamplingFourier + L2Penalty / SingleCoil
             ops.ald_singlecoil_step(st["x"][:B], st["x"][B:], grad[:B], grad[B:], st["y"], st["mask"], st["sc_mode"],
                                     noise_re=st["noise_re"], noise_im=st["noise_im"], seed=st["seed"],
-                                    sample_offset=st["sample_offset"], dev_sched=st["sched_dev"])
+                                    sample_offset=st["sample_offset"], dev_sched=st["sched_dev"], work=st["work"])
 
     def _check_fast_path(self, kwargs):
         """-> sc_mode: None for SENSE + L2Penalty, the ipdm_singlecoil_prox_f32 mode for the single-coil operators
@@ -219,7 +219,7 @@ class ALDInvSegProximalRealImag(ALDOptimizer):
 
         st = dict(x=x, B=B, y=meas, sc_mode=sc_mode, sens=lin.sens_f32(dev) if sc_mode is None else None,
                   mask=lin.mask_u8(dev),
-                  work=torch.empty(B * H * W * 2, dtype=torch.float32, device=dev) if sc_mode is None else None,
+                  work=ops.sense_workspace(B, lin.sens_maps.shape[0] if sc_mode is None else 1, H, W, dev),
                   labels=torch.zeros(2 * B, dtype=torch.long, device=dev),
                   noise_re=None, noise_im=None, seed=kwargs.get("seed", 0),
                   sample_offset=kwargs.get("sample_offset", 0),

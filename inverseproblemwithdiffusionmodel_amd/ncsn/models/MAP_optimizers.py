@@ -50,7 +50,7 @@ class MAPOptimizer(object):
         sens, mask = tfm.sens_f32(dev), tfm.mask_u8(dev)
         m, v = torch.zeros_like(x), torch.zeros_like(x)
         px = torch.empty_like(x)
-        work = torch.empty(B * H * W * 2, dtype=torch.float32, device=dev)
+        work = ops.sense_workspace(B, sens.shape[0], H, W, dev)
         labels = torch.ones(2 * B, dtype=torch.long, device=dev)
         n_iters = self.config.MAP.n_iters
         for it in range(n_iters):
@@ -145,7 +145,7 @@ class MAPOptimizer2DTime(object):
         sens, mask = tfm.sens_f32(dev), tfm.mask_u8(dev)
         m, v = torch.zeros_like(xs), torch.zeros_like(xs)
         px = torch.empty_like(xs)
-        work = torch.empty(N * H * W * 2, dtype=torch.float32, device=dev)
+        work = ops.sense_workspace(N, sens.shape[0], H, W, dev)
         labels = torch.ones(2 * N, dtype=torch.long, device=dev)
         pw, wS, wT = P["prior_weight"], P["spatial_step_weight"], P["temporal_step_weight"]
         for it in range(P["num_iters"]):

@@ -114,14 +114,25 @@ def sense_forward(x, sens_f32, mask_u8):
     return y
 
 
+def sense_workspace(B, n_coils, H, W, device):
+    """scratch tensor for the SENSE / single-coil operators at this size (None when the kernels need none)"""
+    nbytes = _lib.lib.ipdm_sense_workspace_bytes(B, n_coils, H, W)
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device) if nbytes else None
+
+
+def _large_image(H, W):
+    return H * W > 16384
+
+
 def sense_adjoint(s, sens_f32, mask_u8=None, apply_mask=False):
     s = _gpu(s, torch.complex64, "s")
     n = s.shape[0]
     H, W = s.shape[-2:]
     B = s[0].numel() // (H * W)
     x = torch.empty(tuple(s.shape[1:]), dtype=torch.complex64, device=s.device)
+    ws = sense_workspace(B, n, H, W, s.device) if _large_image(H, W) else None
     call("ipdm_sense_adjoint_c64", _ptr(s), _ptr(sens_f32), _ptr(mask_u8), 1 if mask_u8 is None else mask_u8.shape[0],
-         int(bool(apply_mask)), _ptr(x), B, n, H, W, _stream())
+         int(bool(apply_mask)), _ptr(x), _ptr(ws), B, n, H, W, _stream())
     return x
 
 
@@ -131,7 +142,8 @@ def sense_ssos(s):
     H, W = s.shape[-2:]
     B = s[0].numel() // (H * W)
     out = torch.empty(tuple(s.shape[1:]), dtype=torch.float32, device=s.device)
-    call("ipdm_sense_ssos_c64", _ptr(s), _ptr(out), B, n, H, W, _stream())
+    ws = sense_workspace(B, n, H, W, s.device) if _large_image(H, W) else None
+    call("ipdm_sense_ssos_c64", _ptr(s), _ptr(out), _ptr(ws), B, n, H, W, _stream())
     return out
 
 
@@ -142,7 +154,7 @@ def sense_l2prox(z_re, z_im, y, sens_f32, mask_u8, coef, out_re=None, out_im=Non
     B = z_re.numel() // (H * W)
     out_re = torch.empty_like(z_re) if out_re is None else out_re
     out_im = torch.empty_like(z_im) if out_im is None else out_im
-    work = torch.empty(B * H * W * 2, dtype=torch.float32, device=z_re.device) if work is None else work
+    work = sense_workspace(B, sens_f32.shape[0], H, W, z_re.device) if work is None else work
     call("ipdm_sense_l2prox_f32", _ptr(z_re), _ptr(z_im), _ptr(y), _ptr(sens_f32), _ptr(mask_u8), mask_u8.shape[0],
          float(coef), _ptr(out_re), _ptr(out_im), _ptr(work), B, sens_f32.shape[0], H, W, _stream())
     return out_re, out_im
@@ -170,7 +182,7 @@ def ald_sense_step(x_re, x_im, g_re, g_im, y, sens_f32, mask_u8, work, step=0.0,
 SC_L2PENALTY, SC_CLOSED_FORM, SC_PROJECTION = 0, 1, 2
 
 
-def singlecoil_prox(z_re, z_im, y, mask_u8, coef, mode, out_re=None, out_im=None):
+def singlecoil_prox(z_re, z_im, y, mask_u8, coef, mode, out_re=None, out_im=None, work=None):
     """single-coil data consistency on planar real / imaginary planes (modes: ipdm.h, ipdm_singlecoil_prox_f32)"""
     z_re, z_im = _gpu(z_re, torch.float32, "z_re"), _gpu(z_im, torch.float32, "z_im")
     y = _gpu(y, torch.complex64, "y")
@@ -180,22 +192,26 @@ def singlecoil_prox(z_re, z_im, y, mask_u8, coef, mode, out_re=None, out_im=None
         raise ValueError(f"singlecoil_prox: measurement {tuple(y.shape)} does not match the image batch {tuple(z_re.shape)}")
     out_re = torch.empty_like(z_re) if out_re is None else out_re
     out_im = torch.empty_like(z_im) if out_im is None else out_im
+    if work is None and _large_image(H, W):
+        work = sense_workspace(B, 1, H, W, z_re.device)
     call("ipdm_singlecoil_prox_f32", _ptr(z_re), _ptr(z_im), _ptr(y), _ptr(mask_u8), mask_u8.shape[0], float(coef),
-         int(mode), _ptr(out_re), _ptr(out_im), B, H, W, _stream())
+         int(mode), _ptr(out_re), _ptr(out_im), _ptr(work), B, H, W, _stream())
     return out_re, out_im
 
 
 def ald_singlecoil_step(x_re, x_im, g_re, g_im, y, mask_u8, mode, step=0.0, noise_scale=0.0, coef=0.0, noise_re=None,
-                        noise_im=None, seed=0, sample_offset=0, step_id=0, dev_sched=None):
+                        noise_im=None, seed=0, sample_offset=0, step_id=0, dev_sched=None, work=None):
     """in place on x_re / x_im (contiguous float32 GPU planes)"""
     for t, n in ((x_re, "x_re"), (x_im, "x_im"), (g_re, "g_re"), (g_im, "g_im")):
         _inplace_operand(t, torch.float32, n)
     _inplace_operand(y, torch.complex64, "y")
     H, W = x_re.shape[-2:]
     B = x_re.numel() // (H * W)
+    if work is None and _large_image(H, W):
+        work = sense_workspace(B, 1, H, W, x_re.device)
     call("ipdm_ald_singlecoil_step_f32", _ptr(x_re), _ptr(x_im), _ptr(g_re), _ptr(g_im), _ptr(noise_re), _ptr(noise_im),
          float(step), float(noise_scale), int(seed), int(sample_offset), int(step_id), _ptr(dev_sched), _ptr(y),
-         _ptr(mask_u8), mask_u8.shape[0], float(coef), int(mode), B, H, W, _stream())
+         _ptr(mask_u8), mask_u8.shape[0], float(coef), int(mode), _ptr(work), B, H, W, _stream())
 
 
 def langevin_step(x, g, step=0.0, noise_scale=0.0, noise=None, seed=0, sample_offset=0, step_id=0, dev_sched=None):

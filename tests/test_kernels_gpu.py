@@ -263,6 +263,112 @@ def test_ald_singlecoil_step_matches_oracle(ops):
         ops.ald_singlecoil_step(x_re[:, :, :, ::2], x_im, dev(g[0]), dev(g[1]), dev(y), m8, 0)   # strided in-place operand
 
 
+@pytest.mark.parametrize("H,W", [(256, 256), (128, 256), (512, 64)])
+def test_large_image_kspace_ops_vs_oracle(ops, H, W):
+    """images beyond one CU's LDS (the reference's real ACDC slices are 256x256, helpers/load_data.py:274): row / column
+    pass FFT, SENSE forward / adjoint / SSOS, the L2Penalty proximal, the fused Langevin + proximal step (device schedule,
+    injected and Philox noise) and the single-coil operators, all against the CPU oracle"""
+    rng = np.random.default_rng(25)
+    B, n = 3, 4
+    x = (rng.standard_normal((B, 1, H, W)) + 1j * rng.standard_normal((B, 1, H, W))).astype(np.complex64)
+    k = ops.fft2c(dev(x))
+    np.testing.assert_allclose(k.cpu().numpy(), kspace.fft2c(x), atol=2e-5)
+    np.testing.assert_allclose(ops.fft2c(k, inverse=True).cpu().numpy(), x, atol=2e-5)
+    xin = dev(x)
+    assert torch.equal(ops.fft2c(xin), k)                                  # same launch sequence, same bits
+    maps = kspace.sens_maps(n, H, W, 0)
+    mask = kspace.generate_mask(1, W, seed=0, **kspace.MASK_PARAMS["R8" if W < 128 else "R20"])
+    sens, m8 = dev(maps.astype(np.float32)), dev(mask.astype(np.uint8))
+    Ax = ops.sense_forward(dev(x), sens, m8).cpu().numpy()
+    np.testing.assert_allclose(Ax, kspace.sense_forward(x, maps, mask[None]), atol=3e-5)
+    s = (rng.standard_normal((n, B, 1, H, W)) + 1j * rng.standard_normal((n, B, 1, H, W))).astype(np.complex64)
+    np.testing.assert_allclose(ops.sense_adjoint(dev(s), sens).cpu().numpy(), kspace.sense_adjoint(s, maps), atol=3e-5)
+    np.testing.assert_allclose(ops.sense_ssos(dev(s)).cpu().numpy(), kspace.sense_ssos(s, maps), atol=3e-5)
+    AHs = ops.sense_adjoint(dev(s), sens, m8, apply_mask=True).cpu().numpy().astype(np.complex128)
+    lhs, rhs = np.vdot(s.astype(np.complex128), Ax.astype(np.complex128)), np.vdot(AHs, x.astype(np.complex128))
+    assert abs(lhs - rhs) < 1e-4 * abs(lhs)                                # <s, A x> = <A^H s, x>
+    # L2Penalty closed form and the fused step
+    img = (rng.random((1, 1, H, W)) * np.exp(1j * rng.standard_normal((1, 1, H, W)))).astype(np.complex64)
+    y = np.repeat(kspace.sense_forward(img, maps, mask[None]), B, axis=1)
+    g = rng.standard_normal((2, B, 1, H, W)).astype(np.float32)
+    nz = rng.standard_normal((2, B, 1, H, W)).astype(np.float32)
+    step, ns, alpha = np.float32(0.37), np.float32(np.sqrt(2 * 0.37)), 60.0
+    coef = 0.05 * alpha / (n * W)
+    z = ((x.real + step * g[0] + nz[0] * ns) + 1j * (x.imag + step * g[1] + nz[1] * ns)).astype(np.complex64)
+    want = kspace.l2_penalty_sense(z, y, alpha, 1.0, maps, mask[None])
+    assert np.abs(want - z).max() > 1e-3
+    o_re, o_im = ops.sense_l2prox(dev(z.real), dev(z.imag), dev(y), sens, m8, coef)
+    np.testing.assert_allclose(o_re.cpu().numpy() + 1j * o_im.cpu().numpy(), want, atol=2e-5)
+    work = ops.sense_workspace(B, n, H, W, "cuda")
+    assert work.numel() * 4 == n * B * H * W * 8
+    x_re, x_im = dev(x.real), dev(x.imag)
+    sched = np.zeros(1, dtype=[("step", "f4"), ("ns", "f4"), ("coef", "f4"), ("sigma", "f4"), ("id", "i8")])
+    sched["step"], sched["ns"], sched["coef"], sched["id"] = step, ns, coef, 5
+    ops.ald_sense_step(x_re, x_im, dev(g[0]), dev(g[1]), dev(y), sens, m8, work, noise_re=dev(nz[0]), noise_im=dev(nz[1]),
+                       dev_sched=dev(sched.view(np.uint8)))
+    np.testing.assert_allclose(x_re.cpu().numpy() + 1j * x_im.cpu().numpy(), want, atol=2e-5)
+    # Philox noise, keyed as the 128x128 kernel keys it: (seed, sample_offset + b, step id, plane, quad)
+    x_re, x_im = dev(x.real), dev(x.imag)
+    ops.ald_sense_step(x_re, x_im, dev(g[0]), dev(g[1]), dev(y), sens, m8, work, step=float(step), noise_scale=float(ns),
+                       coef=0.0, seed=9, sample_offset=4, step_id=77)
+    n0 = ops.philox_normal((B, H * W), "cuda", seed=9, sample_offset=4, step_id=77, plane=0).cpu().numpy().reshape(B, 1, H, W)
+    n1 = ops.philox_normal((B, H * W), "cuda", seed=9, sample_offset=4, step_id=77, plane=1).cpu().numpy().reshape(B, 1, H, W)
+    np.testing.assert_allclose(x_re.cpu().numpy(), x.real + step * g[0] + n0 * ns, atol=3e-6)
+    np.testing.assert_allclose(x_im.cpu().numpy(), x.imag + step * g[1] + n1 * ns, atol=3e-6)
+    # single-coil operators
+    ysc = np.repeat((mask * kspace.fft2c(img)).astype(np.complex64), B, axis=0)
+    for mode, a, ref in [(ops.SC_L2PENALTY, 30.0, kspace.l2_penalty_single(z, ysc, 30.0, 1.0, mask)),
+                         (ops.SC_CLOSED_FORM, 0.7, kspace.single_coil(z, ysc, 0.7, 1.0, mask))]:
+        c = 0.05 * a / B if mode == ops.SC_L2PENALTY else a
+        o_re, o_im = ops.singlecoil_prox(dev(z.real), dev(z.imag), dev(ysc), m8, c, mode)
+        np.testing.assert_allclose(o_re.cpu().numpy() + 1j * o_im.cpu().numpy(), ref, atol=3e-5)
+        x_re, x_im = dev(x.real), dev(x.imag)
+        ops.ald_singlecoil_step(x_re, x_im, dev(g[0]), dev(g[1]), dev(ysc), m8, mode, step=float(step), noise_scale=float(ns),
+                                coef=c, noise_re=dev(nz[0]), noise_im=dev(nz[1]))
+        np.testing.assert_allclose(x_re.cpu().numpy() + 1j * x_im.cpu().numpy(), ref, atol=3e-5)
+    lam = 0.3
+    kz = kspace.fft2c(z)
+    want = kspace.ifft2c(lam * ysc + (1 - lam) * mask * kz + (1 - mask) * kz)
+    o_re, o_im = ops.singlecoil_prox(dev(z.real), dev(z.imag), dev(ysc), m8, lam, ops.SC_PROJECTION)
+    np.testing.assert_allclose(o_re.cpu().numpy() + 1j * o_im.cpu().numpy(), want, atol=3e-5)
+
+
+def test_sense_sampler_256(ops):
+    """the SENSE sampler end to end at the reference's real ACDC size (256x256, 4 coils): tiny score net, 3 levels, graph
+    and eager bit-equal, and equal to the CPU oracle under the same injected noise"""
+    from argparse import Namespace
+    from inverseproblemwithdiffusionmodel_amd import engine
+    from inverseproblemwithdiffusionmodel_amd.ncsn.models.ncsnv2 import NCSNv2Deepest
+    from inverseproblemwithdiffusionmodel_amd.synthetic import synth_state_dict
+    from oracle import scorenet as oracle_net, ald as oracle_ald, metrics
+    devc = torch.device("cuda")
+    H = W = 256
+    cfg = engine.acdc_config(devc, H)
+    cfg.model.ngf, cfg.model.num_classes, cfg.model.sigma_begin = 8, 12, 2.0
+    cfg.recons.num_classes, cfg.recons.sigma_begin = 12, 2.0
+    net = NCSNv2Deepest(cfg)
+    net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=1), strict=False)
+    net = net.to(devc).eval()
+    prob = engine.build_problem(devc, 2, R=20, H=H, W=W, scorenet=net, cfg=cfg, lr_scaled=2e6)
+    gen = torch.Generator().manual_seed(5)
+    tape = [torch.randn(2, 1, H, W, generator=gen) for _ in range(18)]
+    runs = []
+    for use_graph in (True, False):
+        it = iter(tape)
+        runs.append(prob.sampler(**prob.call_kwargs, noise_fn=lambda like: next(it), n_levels=3, use_graph=use_graph)[0])
+    assert torch.equal(runs[0], runs[1])
+    sd_cpu = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    it2 = iter(tape)
+    with torch.no_grad():
+        x_cpu = oracle_ald.ald_sense_real_imag(
+            lambda x, lab: oracle_net.ncsnv2_deepest(x, lab, sd_cpu), prob.sigmas.cpu().numpy(),
+            prob.measurement.cpu().numpy(), prob.op.sens_maps.numpy(), prob.op.random_under_fourier.mask.numpy(),
+            cfg.sampling.step_lr, 3, 2e6, False, lambda like: next(it2), n_levels=3)
+    x_gpu = runs[0].numpy()
+    assert metrics.nrmse(np.abs(x_gpu), np.abs(x_cpu)) < 1e-3
+    np.testing.assert_allclose(x_gpu, x_cpu, atol=1e-3 * np.abs(x_cpu).max())
+
+
 def test_inplace_wrappers_reject_bad_operands(ops):
     """in-place kernels must not silently update a contiguous copy nor read a wrong dtype as raw memory"""
     x = torch.zeros(2, 8, 8, device="cuda")
