@@ -306,6 +306,25 @@ int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const float* bias, c
                              float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
                              void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * On-device reporting (reference: helpers/metrics.py:21-102, helpers/visualizations.py:93,117,121).  Deterministic
+ * float64 reductions; metrics are per image (one result per image in `out`, device float64).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* out[i] = |x[i]| */
+int ipdm_magnitude_c64(const float* x /* n complex64 */, float* out, int64_t n, void* stream);
+/* samples [n_samples][HW] complex64 -> planes [6][HW] float32: sum |x|, sum |x|^2, sum angle, sum angle^2, sum Re,
+ * sum Im over the samples (compute_mean_and_std, helpers/metrics.py:77-92, as partial sums a shard can all-reduce) */
+int ipdm_posterior_moments_c64(const float* samples, float* planes, int n_samples, int64_t HW, void* stream);
+/* NRMSE_wrapper (helpers/metrics.py:70-74): skimage normalized_root_mse(img, ref, "euclidean") = ||img - ref|| / ||img||,
+ * img [n_images][elems]; ref [n_images][elems] or one [elems] image shared by all (ref_broadcast) */
+int ipdm_nrmse_f32(const float* img, const float* ref, double* out, int n_images, int64_t elems, int ref_broadcast,
+                   void* stream);
+/* SSIM_wrapper (helpers/metrics.py:55-67) on single-channel [H][W] images: skimage structural_similarity defaults
+ * (7x7 uniform window, K1 0.01, K2 0.03, sample covariance, mean over the valid interior) with an explicit data_range */
+int ipdm_ssim_f32(const float* img, const float* ref, double* out, int n_images, int H, int W, int ref_broadcast,
+                  double data_range, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

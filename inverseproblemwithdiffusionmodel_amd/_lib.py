@@ -14,7 +14,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: libipdm.so then bi
 from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libipdm.so")
+LIB_PATH = os.environ.get("IPDM_LIB") or os.path.join(_HERE, "libipdm.so")     # IPDM_LIB: a diagnostic build (scripts/build_variant.sh)
 
 P = c_void_p   # device pointer
 
@@ -74,6 +74,10 @@ SIGNATURES = {
     "ipdm_conv_wino_bx3_pack_weight": [P, P, c_int, c_int, P],
     "ipdm_conv2d_wino_bx3_supported": [c_int, c_int, c_int, c_int, c_int],
     "ipdm_conv2d_wino_bx3_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "ipdm_magnitude_c64": [P, P, c_int64, P],
+    "ipdm_posterior_moments_c64": [P, P, c_int, c_int64, P],
+    "ipdm_nrmse_f32": [P, P, P, c_int, c_int64, c_int, P],
+    "ipdm_ssim_f32": [P, P, P, c_int, c_int, c_int, c_int, ctypes.c_double, P],
 }
 _RESTYPES = {"ipdm_build_arch": c_char_p, "ipdm_fft2c_workspace_bytes": c_int64, "ipdm_sense_workspace_bytes": c_int64, "ipdm_conv_bx3_weight_bytes": c_int64,
              "ipdm_conv_wino_bx3_weight_bytes": c_int64}

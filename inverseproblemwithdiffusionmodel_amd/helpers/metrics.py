@@ -2,7 +2,9 @@
 calls scikit-image (not installed here); these are numpy restatements of skimage's published algorithms:
 ``normalized_root_mse(image_true, image_test, 'euclidean')`` -- NB the reference passes the RECONSTRUCTION first,
 so it is the normaliser (:72) -- and ``structural_similarity`` with its defaults (7x7 uniform window, K1 0.01,
-K2 0.03, sample covariance, mean over the valid interior).  Host-side analysis code, not on the sampling path."""
+K2 0.03, sample covariance, mean over the valid interior).  The numpy functions keep the reference's host API; the
+``*_device`` functions below run the same definitions on the GPU (libipdm.so: ipdm_nrmse_f32, ipdm_ssim_f32,
+ipdm_posterior_moments_c64, ipdm_magnitude_c64) so that a 105-sample study is scored without a host round trip."""
 from collections import defaultdict
 from typing import Dict, List
 
@@ -76,3 +78,45 @@ def compute_snr(imgs: np.ndarray):
     imgs = np.abs(imgs)
     axes = tuple(range(1, len(imgs.shape)))
     return 20 * np.log10(imgs.max(axis=axes) / np.std(imgs, axis=axes))
+
+
+# ---- on-device variants -----------------------------------------------------------------------
+def _magnitude_device(x):
+    import torch
+    from .. import ops
+    if x.is_complex():
+        return ops.magnitude(x.to(torch.complex64).contiguous())
+    return x.float().contiguous()
+
+
+def compute_metrics_device(metric_names: List[str], img, img_orig, reduce=None, data_range: float = 2.0):
+    """compute_metrics on GPU tensors.  img (B, 1, H, W) (complex: scored on magnitudes, as helpers/visualizations.py:93),
+    img_orig (1 or B, 1, H, W).  Returns {name: float64 numpy array (B,)} (or the reduced scalar)."""
+    from .. import ops
+    if not img.is_cuda:
+        raise RuntimeError("compute_metrics_device: expected GPU tensors (use compute_metrics for numpy arrays)")
+    a, b = _magnitude_device(img), _magnitude_device(img_orig.to(img.device))
+    if a.dim() != 4 or a.shape[1] != 1:
+        raise NotImplementedError("device metrics score single-channel (B, 1, H, W) images")
+    out = {}
+    for name in metric_names:
+        if name == "NRMSE":
+            v = ops.nrmse(a, b)
+        elif name == "SSIM":
+            v = ops.ssim(a, b, data_range)
+        elif name == "MAE":
+            v = (a - b).abs().double().mean(dim=(1, 2, 3))
+        else:
+            raise KeyError(name)
+        v = v.cpu().numpy()
+        out[name] = REGISTERED_REDUCTION[reduce](v) if reduce is not None else v
+    return out
+
+
+def compute_mean_and_std_device(imgs):
+    """compute_mean_and_std for a (B, C, H, W) complex GPU tensor -> (mag_mean, phase_mean, mag_std, phase_std) GPU tensors
+    (population std, as np.std), from the six moment planes of one kernel"""
+    from .. import sharding
+    assert imgs.shape[0] > 1 and imgs.is_complex()
+    post = sharding.posterior_from_moments(sharding.moment_planes(imgs), imgs.shape[0])
+    return post["mag_mean"], post["phase_mean"], post["mag_std"], post["phase_std"]

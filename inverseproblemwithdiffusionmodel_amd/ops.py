@@ -238,6 +238,51 @@ def philox_normal(shape, device, seed=0, sample_offset=0, step_id=0, plane=0):
     return out
 
 
+# ---- on-device reporting ------------------------------------------------------------------------
+def magnitude(x):
+    x = _gpu(x, torch.complex64, "x")
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    call("ipdm_magnitude_c64", _ptr(x), _ptr(out), x.numel(), _stream())
+    return out
+
+
+def posterior_moment_planes(samples):
+    """samples (n, ..., H, W) complex64 -> (6, ..., H, W) float32 partial sums over the n samples:
+    sum |x|, sum |x|^2, sum angle, sum angle^2, sum Re, sum Im"""
+    samples = _gpu(samples, torch.complex64, "samples")
+    n = samples.shape[0]
+    hw = samples[0].numel() if n else 0
+    planes = torch.empty((6,) + tuple(samples.shape[1:]), dtype=torch.float32, device=samples.device)
+    call("ipdm_posterior_moments_c64", _ptr(samples), _ptr(planes), n, hw, _stream())
+    return planes
+
+
+def nrmse(img, ref):
+    """per-image ||img - ref|| / ||img|| (the reference's argument order); img (n, ...), ref same shape or one image"""
+    img, ref = _gpu(img, torch.float32, "img"), _gpu(ref, torch.float32, "ref")
+    n = img.shape[0]
+    elems = img[0].numel()
+    bcast = ref.numel() == elems
+    if not bcast and ref.numel() != img.numel():
+        raise ValueError(f"nrmse: reference {tuple(ref.shape)} does not match {tuple(img.shape)}")
+    out = torch.empty(n, dtype=torch.float64, device=img.device)
+    call("ipdm_nrmse_f32", _ptr(img), _ptr(ref), _ptr(out), n, elems, int(bcast), _stream())
+    return out
+
+
+def ssim(img, ref, data_range=2.0):
+    """per-image mean SSIM of single-channel images (n, H, W) (or (n, 1, H, W)) against ref (same shape or one image)"""
+    img, ref = _gpu(img, torch.float32, "img"), _gpu(ref, torch.float32, "ref")
+    H, W = img.shape[-2:]
+    n = img.numel() // (H * W)
+    bcast = ref.numel() == H * W
+    if not bcast and ref.numel() != img.numel():
+        raise ValueError(f"ssim: reference {tuple(ref.shape)} does not match {tuple(img.shape)}")
+    out = torch.empty(n, dtype=torch.float64, device=img.device)
+    call("ipdm_ssim_f32", _ptr(img), _ptr(ref), _ptr(out), n, H, W, int(bcast), float(data_range), _stream())
+    return out
+
+
 # ---- score-network glue -----------------------------------------------------------------------
 def instnorm_plus_coef(x, alpha, gamma, beta):
     """x [B, C, *spatial] (2-D images or 3-D volumes: the statistics run over all spatial positions)"""

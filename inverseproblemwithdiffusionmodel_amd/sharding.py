@@ -22,7 +22,11 @@ def shard_range(total, world_size, rank):
 
 def moment_planes(samples):
     """samples (n, 1, H, W) complex -> (6, 1, H, W) float32 partial sums:
-    sum|x|, sum|x|^2, sum angle, sum angle^2, sum Re, sum Im  (helpers/metrics.py:77-92 semantics)."""
+    sum|x|, sum|x|^2, sum angle, sum angle^2, sum Re, sum Im  (helpers/metrics.py:77-92 semantics).
+    GPU tensors: one kernel (ipdm_posterior_moments_c64); CPU tensors (the gloo tests): the same sums in torch."""
+    if samples.is_cuda:
+        from . import ops
+        return ops.posterior_moment_planes(samples.to(torch.complex64).contiguous())
     mag, ph = samples.abs().float(), samples.angle().float()
     return torch.stack([mag.sum(0), (mag * mag).sum(0), ph.sum(0), (ph * ph).sum(0),
                         samples.real.float().sum(0), samples.imag.float().sum(0)])

@@ -231,3 +231,57 @@ def test_conv_dispatch_host_rules():
     assert sk(28, 1, 256, 256, 16, 16, 3, 1) == 2 and sk(26, 1, 256, 256, 16, 16, 3, 1) == 2     # both shard sizes split alike
     assert sk(210, 1, 256, 256, 16, 16, 3, 1) == 1 and sk(1, 1, 512, 512, 4, 4, 3, 1) == 4
     assert sk(1, 1, 128, 128, 16, 16, 3, 1) == 1 and sk(28, 1, 256, 256, 32, 32, 3, 1) == 1       # one group / wide image
+
+
+def test_real_data_front_end(tmp_path):
+    """ACDC slice .npz and CINE .mat front ends + add_phase on synthetic files written in the reference's on-disk formats
+    (helpers/load_data.py:125-164, 167-226, 241-283, 372-397).  The MONAI transforms are restated (parity unpinned): the
+    test pins the file handling, the split logic, shapes / dtypes / ranges and the foreground crop."""
+    import scipy.io as sio
+    from inverseproblemwithdiffusionmodel_amd.helpers import load_data as ld
+    rng = np.random.default_rng(0)
+    vol_dir, slice_dir = tmp_path / "vols", tmp_path / "slices"
+    vol_dir.mkdir()
+    for v in range(5):
+        img = np.zeros((1, 3, 40, 36), np.float32)
+        img[:, :, 8:30, 5:33] = rng.random((1, 3, 22, 28)).astype(np.float32) * 900 + 1
+        lab = np.zeros_like(img, dtype=np.int64)
+        lab[:, :, 12:20, 10:18] = 3
+        lab[:, :, 20:24, 10:18] = 2
+        np.savez(vol_dir / f"pat{v:02d}.npz", image=img, multiClassMasks=lab, PD=img, T1=img, T2=img)
+    ld.vol2slice(str(vol_dir), str(slice_dir))
+    assert len(list(slice_dir.glob("*.npz"))) == 15
+    sizes = {m: len(ld.load_ACDC(str(slice_dir), mode=m, if_aug=False)) for m in ("train", "val", "test")}
+    assert sizes == {"train": 12, "val": 1, "test": 2}
+    ds = ld.load_data("ACDC", "train", root_dir=str(slice_dir), if_aug=False)
+    d = ds[0]
+    img, lab = d[ld.IMAGE_KEY], d[ld.LABEL_KEY]
+    assert img.shape == (1, 256, 256) and img.dtype == torch.float32 and lab.shape == (1, 256, 256) and lab.dtype == torch.int64
+    assert 0.0 <= float(img.min()) and float(img.max()) <= 1.0 and set(lab.unique().tolist()) <= {0, 1}
+    assert float((img > 0).float().mean()) > 0.95          # cropped to the foreground box before resizing
+    assert 0.05 < float(lab.float().mean()) < 0.2           # class 3 only: 8x8 of the 22x28 box
+    # same files, same seed -> same split as python's random.shuffle of the glob order
+    import glob, random
+    names = glob.glob(str(slice_dir / "*.npz"))
+    random.seed(0)
+    random.shuffle(names)
+    assert ds.filenames == names[:12]
+    # CINE .mat: (H, W, T, N)
+    cine_dir = tmp_path / "cine"
+    cine_dir.mkdir()
+    sio.savemat(cine_dir / "cine_test_small.mat", {"imgs": rng.random((32, 32, 6, 2)) * 50 + 3})
+    frames = ld.load_cine(str(cine_dir), mode="val", resize_shape=16)
+    assert frames.tensors[0].shape == (12, 1, 16, 16)
+    series = ld.load_cine(str(cine_dir), mode="test", flatten_type="temporal", win_size=8)
+    assert series.tensors[0].shape == (2 * 16, 64, 6)
+    x = series.tensors[0]
+    assert float(x.min()) >= 0.0 and float(x.max()) <= 1.0
+    # add_phase: magnitude preserved, deterministic under a seed, smooth (the 5x5 patch upsampled bicubically)
+    mag = torch.rand(2, 1, 64, 64)
+    a, b = ld.add_phase(mag, (5, 5), seed=3), ld.add_phase(mag, (5, 5), seed=3)
+    assert a.dtype == torch.complex64 and torch.equal(a, b) and torch.allclose(a.abs(), mag, atol=1e-6)
+    ph = torch.angle(a[0, 0] / mag[0, 0].clamp_min(1e-6))
+    vol = ld.add_phase(torch.rand(6, 1, 32, 32), (2, 3, 3), seed=1, mode="2D+time")
+    assert vol.shape == (6, 1, 32, 32) and vol.dtype == torch.complex64
+    with pytest.raises(FileNotFoundError):
+        ld.load_data("ACDC", "val")

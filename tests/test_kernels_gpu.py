@@ -733,3 +733,45 @@ def test_conv2d_winograd_bx3(ops, B, Cin, Cout, H, W, res, dil):
     # repeated launches are bit-identical (no race between the DMA refill, the transform and the MFMA reads)
     raw2 = ops.conv2d_wino_bx3(x.cuda(), U, bias.cuda(), None if resid is None else resid.cuda(), dilation=dil)
     assert torch.equal(raw, raw2)
+
+
+# ---- on-device reporting ---------------------------------------------------------------------------------------------
+def test_device_metrics_match_host_definitions(ops):
+    """NRMSE / SSIM / posterior mean-std on the GPU against the numpy definitions of helpers/metrics.py (the reference's
+    argument order: the reconstruction normalises NRMSE) and against a direct per-window float64 evaluation of SSIM"""
+    from inverseproblemwithdiffusionmodel_amd.helpers import metrics as hm
+    from oracle import metrics as om
+    rng = np.random.default_rng(31)
+    B, H, W = 5, 48, 40
+    ref = (rng.random((1, 1, H, W)) * np.exp(1j * rng.standard_normal((1, 1, H, W)))).astype(np.complex64)
+    rec = (ref + 0.05 * (rng.standard_normal((B, 1, H, W)) + 1j * rng.standard_normal((B, 1, H, W)))).astype(np.complex64)
+    got = hm.compute_metrics_device(["NRMSE", "SSIM", "MAE"], dev(rec), dev(ref))
+    want = hm.compute_metrics(["NRMSE", "SSIM", "MAE"], np.abs(rec), np.abs(ref))
+    for k in ("NRMSE", "SSIM", "MAE"):
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-6, atol=1e-9, err_msg=k)
+    assert abs(float(got["NRMSE"][0]) - om.nrmse(np.abs(rec[0]), np.abs(ref[0]))) < 1e-9
+    # direct window evaluation of one SSIM map entry and of the mean (independent of scipy's uniform_filter)
+    a, b = np.abs(rec[1, 0]).astype(np.float64), np.abs(ref[0, 0]).astype(np.float64)
+    tot = 0.0
+    for oy in range(H - 6):
+        for ox in range(W - 6):
+            wa, wb = a[oy:oy + 7, ox:ox + 7], b[oy:oy + 7, ox:ox + 7]
+            ux, uy = wa.mean(), wb.mean()
+            vx, vy = wa.var(ddof=1), wb.var(ddof=1)
+            vxy = ((wa - ux) * (wb - uy)).sum() / 48.0
+            tot += ((2 * ux * uy + 0.02 ** 2) * (2 * vxy + 0.06 ** 2)) / ((ux ** 2 + uy ** 2 + 0.02 ** 2) * (vx + vy + 0.06 ** 2))
+    assert abs(float(got["SSIM"][1]) - tot / ((H - 6) * (W - 6))) < 1e-8     # one-pass float64 window moments
+    # per-image references and the reduce= path
+    refs = np.repeat(ref, B, axis=0) * (1 + 0.1 * np.arange(B))[:, None, None, None].astype(np.float32)
+    got2 = hm.compute_metrics_device(["NRMSE", "SSIM"], dev(rec), dev(refs.astype(np.complex64)), reduce="mean")
+    want2 = hm.compute_metrics(["NRMSE", "SSIM"], np.abs(rec), np.abs(refs), reduce="mean")
+    for k in ("NRMSE", "SSIM"):
+        assert abs(got2[k] - want2[k]) < 1e-6
+    # posterior panels
+    mm, pm, ms, ps = (t.cpu().numpy() for t in hm.compute_mean_and_std_device(dev(rec)))
+    wm, wp, ws_, wps = hm.compute_mean_and_std(rec)
+    np.testing.assert_allclose(mm, wm, atol=1e-6)
+    np.testing.assert_allclose(pm, wp, atol=2e-6)
+    np.testing.assert_allclose(ms, ws_, atol=2e-5)
+    np.testing.assert_allclose(ps, wps, atol=2e-4)      # E[x^2] - E[x]^2 in float32 on angles of O(pi)
+    np.testing.assert_allclose(ops.magnitude(dev(rec)).cpu().numpy(), np.abs(rec), rtol=1e-6)
