@@ -266,7 +266,8 @@ def main():
         n_wino = sum(1 for r in reps[0] if r.get("wino"))
         # algorithmic HBM bytes of a launch: input + (residual) read once, each requested output written once,
         # weights read once
-        bytes_alg = sum(4.0 * r["B"] * r["H"] * r["W"] * (r["Cin"] + r["Cout"] * (int(r.get("res", False)) + r.get("n_out", 1)))
+        bytes_alg = sum(4.0 * r["B"] * r["H"] * r["W"] * (r["Cin"] + r["Cout"] * (int(r.get("res", False)) + r.get("n_out", 1))
+                                                          * (0.25 if r.get("pool2") else 1.0))
                         + 4.0 * r["Cin"] * r["Cout"] * r["k"] ** 2 for r in reps[0]) / len(reps[0])
         conv_ms = float(np.median([sum(r["ms"] for r in rep) for rep in reps]))
         log(f"conv census: {len(reps[0])} launches, {conv_ms:.2f} ms, {flops / 1e12:.3f} TFLOP per step")

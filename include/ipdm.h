@@ -302,9 +302,12 @@ int ipdm_adam_ascent_f32(float* x, const float* g, float* m, float* v, int64_t n
 int64_t ipdm_conv_wino_bx3_weight_bytes(int Cout, int Cin);
 int ipdm_conv_wino_bx3_pack_weight(const float* w /* [Cout][Cin][3][3] */, void* U, int Cout, int Cin, void* stream);
 int ipdm_conv2d_wino_bx3_supported(int Cin, int Cout, int H, int W, int dilation);
+/* pool2 != 0 (wide images, dilation 1): ConvMeanPool (layers.py:291-313) in one launch -- out / out_act / residual are
+ * [B][Cout][H/2][W/2] and hold the 2x2 mean of the convolution (+ residual, activation); IPDM_EUNSUPPORTED where the
+ * pooled epilogue is not built (the caller then runs the convolution and ipdm_meanpool2_f32 separately) */
 int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
                              float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
-                             void* stream);
+                             int pool2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * On-device reporting (reference: helpers/metrics.py:21-102, helpers/visualizations.py:93,117,121).  Deterministic
@@ -313,9 +316,9 @@ int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const float* bias, c
 
 /* out[i] = |x[i]| */
 int ipdm_magnitude_c64(const float* x /* n complex64 */, float* out, int64_t n, void* stream);
-/* samples [n_samples][HW] complex64 -> planes [6][HW] float32: sum |x|, sum |x|^2, sum angle, sum angle^2, sum Re,
+/* samples [n_samples][HW] complex64 -> planes [6][HW] float64: sum |x|, sum |x|^2, sum angle, sum angle^2, sum Re,
  * sum Im over the samples (compute_mean_and_std, helpers/metrics.py:77-92, as partial sums a shard can all-reduce) */
-int ipdm_posterior_moments_c64(const float* samples, float* planes, int n_samples, int64_t HW, void* stream);
+int ipdm_posterior_moments_c64(const float* samples, double* planes, int n_samples, int64_t HW, void* stream);
 /* NRMSE_wrapper (helpers/metrics.py:70-74): skimage normalized_root_mse(img, ref, "euclidean") = ||img - ref|| / ||img||,
  * img [n_images][elems]; ref [n_images][elems] or one [elems] image shared by all (ref_broadcast) */
 int ipdm_nrmse_f32(const float* img, const float* ref, double* out, int n_images, int64_t elems, int ref_broadcast,

@@ -73,7 +73,7 @@ SIGNATURES = {
     "ipdm_conv_wino_bx3_weight_bytes": [c_int, c_int],
     "ipdm_conv_wino_bx3_pack_weight": [P, P, c_int, c_int, P],
     "ipdm_conv2d_wino_bx3_supported": [c_int, c_int, c_int, c_int, c_int],
-    "ipdm_conv2d_wino_bx3_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "ipdm_conv2d_wino_bx3_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "ipdm_magnitude_c64": [P, P, c_int64, P],
     "ipdm_posterior_moments_c64": [P, P, c_int, c_int64, P],
     "ipdm_nrmse_f32": [P, P, P, c_int, c_int64, c_int, P],

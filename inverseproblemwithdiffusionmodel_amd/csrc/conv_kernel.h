@@ -49,6 +49,8 @@ struct ConvArgs {
   int D, kd;       // depth slices per volume (1 = plain 2-D) and depth taps (1 or 3): 3-D convolution as extra K chunks
   int tiles_x, tiles_y, co_tiles;
   unsigned long long* dbg;   // optional in-kernel stamps (diagnostic builds / IPDM tuning only; NULL in production)
+  int pool2 = 0;             // conv_wino_bx3 wide kernels only: write the 2x2 MEAN of every output tile (ConvMeanPool,
+                             //   layers.py:291-313) to out / out_act [B][Cout][H/2][W/2]; residual is at that size too
   int ksplit = 1;            // conv_bx3 only: the K (input channel x depth tap) chunks are dealt to ksplit workgroups
   float* partial = nullptr;  //   per tile, each writing its raw partial sums to partial[ks][B][Cout][D*H*W]
 };

@@ -721,6 +721,17 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
             tt[1][qq] = m[1 * 4 + qq] - m[2 * 4 + qq] - m[3 * 4 + qq];
           }
           const float bias = a.bias ? a.bias[co] : 0.f;
+          if (a.pool2) {
+            // ConvMeanPool: (y[::2,::2] + y[1::2,::2] + y[::2,1::2] + y[1::2,1::2]) / 4 in the reference's order; the
+            // output tile IS the 2x2 pooling window, so the full-resolution result is never written
+            const float y00 = tt[0][0] + tt[0][1] + tt[0][2] + bias, y01 = tt[0][1] - tt[0][2] - tt[0][3] + bias;
+            const float y10 = tt[1][0] + tt[1][1] + tt[1][2] + bias, y11 = tt[1][1] - tt[1][2] - tt[1][3] + bias;
+            float v = (((y00 + y10) + y01) + y11) * 0.25f;
+            const size_t o = (((size_t)cur_g.b * a.Cout + co) * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1);
+            if (a.residual) v += a.residual[o];
+            if (a.out) a.out[o] = v;
+            if (a.out_act) a.out_act[o] = a.act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, a.act_out);
+          } else {
 #pragma unroll
           for (int ii = 0; ii < 2; ++ii) {
             float y0v = tt[ii][0] + tt[ii][1] + tt[ii][2] + bias;
@@ -737,6 +748,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
               const float e1 = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
               *reinterpret_cast<float2*>(a.out_act + o) = make_float2(e0, e1);
             }
+          }
           }
         }
       }
@@ -1133,6 +1145,9 @@ bool wino_bx3_ok(const ConvArgs& a, int ks) {
 int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
   const bool small = x_small(a);
   const bool small_dma = small && wino_persist() && x_small_dma(a);
+  // the pooled epilogue lives in the persistent wide kernels only (the ConvMeanPool layers of the score nets are 32..128
+  // pixels wide); everything else reports "unsupported" and the caller runs convolution + mean-pool separately
+  if (a.pool2 && (small || !wino_persist() || a.Cin < 2 * X_KC || a.H % 2 || a.W % 2)) return IPDM_EUNSUPPORTED;
   if (small_dma) {
     a.tiles_x = (a.W + 15) / 16;
     a.tiles_y = (a.H + 15) / 16;
@@ -1168,7 +1183,7 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
     const char* e = getenv("IPDM_WBX3_C128");
     use_c128 = e ? atoi(e) : 0;
   }
-  if (use_c128 && wino_persist() && a.Cout % 128 == 0 && a.Cin >= 2 * X_KC && (small_dma || !small)) {
+  if (use_c128 && !a.pool2 && wino_persist() && a.Cout % 128 == 0 && a.Cin >= 2 * X_KC && (small_dma || !small)) {
     // 128 channels x 32 tiles per workgroup: 16 x 2 tiles (4 x 32 pixels) on wide images, 8 x 4 (8 x 16) on small ones
     static bool attr2 = false;
     if (!attr2) {
@@ -1254,7 +1269,7 @@ extern "C" int ipdm_conv2d_wino_bx3_supported(int Cin, int Cout, int H, int W, i
 
 extern "C" int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const float* bias, const float* residual,
                                         float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H, int W,
-                                        int dilation, void* stream) {
+                                        int dilation, int pool2, void* stream) {
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && dilation >= 1);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && U && (out || out_act) && x != out && x != out_act);
@@ -1262,6 +1277,7 @@ extern "C" int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const flo
   a.x = x; a.wt = (const float*)U; a.bias = bias; a.coef = nullptr; a.residual = residual; a.out = out; a.out_act = out_act;
   a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = dilation; a.act = IPDM_ACT_NONE;
   a.D = 1; a.kd = 1; a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
+  a.pool2 = pool2 ? 1 : 0;
   if (!wino_bx3_ok(a, 3)) return IPDM_EUNSUPPORTED;
   return conv_wino_bx3_launch(a, ipdm_stream(stream));
 }

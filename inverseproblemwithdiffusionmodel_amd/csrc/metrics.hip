@@ -26,15 +26,16 @@ __global__ __launch_bounds__(256) void magnitude_kernel(const float2* __restrict
   }
 }
 
-// samples [n][HW] complex64 -> planes [6][HW] float32: sum |x|, sum |x|^2, sum angle, sum angle^2, sum Re, sum Im
-// (sample order 0..n-1 per pixel: the partial sums of a shard are what sharding.all_reduce_posterior adds up)
-__global__ __launch_bounds__(256) void posterior_moments_kernel(const float2* __restrict__ s, float* __restrict__ planes,
+// samples [n][HW] complex64 -> planes [6][HW] float64: sum |x|, sum |x|^2, sum angle, sum angle^2, sum Re, sum Im
+// (sample order 0..n-1 per pixel: the partial sums of a shard are what sharding.all_reduce_posterior adds up; float64
+//  sums, because std = sqrt(E[x^2] - E[x]^2) of angles of O(pi) loses 1e-4 in float32)
+__global__ __launch_bounds__(256) void posterior_moments_kernel(const float2* __restrict__ s, double* __restrict__ planes,
                                                                 int n, int64_t HW) {
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < HW; p += (int64_t)gridDim.x * 256) {
-    float m1 = 0.f, m2 = 0.f, a1 = 0.f, a2 = 0.f, re = 0.f, im = 0.f;
+    double m1 = 0, m2 = 0, a1 = 0, a2 = 0, re = 0, im = 0;
     for (int k = 0; k < n; ++k) {
       const float2 v = s[(size_t)k * HW + p];
-      const float mag = hypotf(v.x, v.y), ang = atan2f(v.y, v.x);
+      const double mag = hypotf(v.x, v.y), ang = atan2f(v.y, v.x);      // float32 |x| and angle, as numpy on complex64
       m1 += mag; m2 += mag * mag; a1 += ang; a2 += ang * ang; re += v.x; im += v.y;
     }
     planes[p] = m1; planes[HW + p] = m2; planes[2 * HW + p] = a1; planes[3 * HW + p] = a2;
@@ -105,7 +106,7 @@ extern "C" int ipdm_magnitude_c64(const float* x, float* out, int64_t n, void* s
   return ipdm_launch_status();
 }
 
-extern "C" int ipdm_posterior_moments_c64(const float* samples, float* planes, int n_samples, int64_t HW, void* stream) {
+extern "C" int ipdm_posterior_moments_c64(const float* samples, double* planes, int n_samples, int64_t HW, void* stream) {
   IPDM_REQUIRE(n_samples >= 0 && HW >= 0);
   if (HW == 0) return IPDM_OK;
   IPDM_REQUIRE(planes && (samples || n_samples == 0));

@@ -14,7 +14,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import ops, _lib
 from .normalization import InstanceNorm2dPlus, get_normalization  # noqa: F401
 
 
@@ -31,6 +31,8 @@ class _Act:
 
 # Winograd F(2x2,3x3) for eligible layers (3x3, dilation 1, wide images); IPDM_WINOGRAD=0 forces the direct kernel
 USE_WINOGRAD = os.environ.get("IPDM_WINOGRAD", "1") != "0"
+# ConvMeanPool (+ shortcut + activation) as one pooled-epilogue launch; IPDM_FUSE_POOL=0 runs conv, mean-pool, add, act apart
+FUSE_POOL = os.environ.get("IPDM_FUSE_POOL", "1") != "0"
 
 
 def get_act(config):
@@ -132,6 +134,20 @@ class ConvMeanPool(nn.Module):
             # the bytes (same value up to fp32 rounding order)
             return self.conv(ops.meanpool2(inputs))
         return ops.meanpool2(self.conv(inputs))
+
+    def fused(self, inputs, residual=None, act_out=ops.ACT_NONE):
+        """3x3 ConvMeanPool (+ pooled-size residual, + activated copy) in ONE launch: the Winograd kernel's 2x2 output tile
+        is the pooling window.  -> out or (out, out_act); None where the pooled epilogue is not built for this layer."""
+        c = self.conv
+        if not (FUSE_POOL and USE_WINOGRAD and ops.CONV_IMPL == "bx3" and c.ndim == 2 and c.kernel_size == 3 and c.dilation == 1
+                and inputs.shape[2] % 2 == 0 and inputs.shape[3] % 2 == 0
+                and ops.wino_bx3_pays(c.in_planes, c.out_planes, inputs.shape[2], inputs.shape[3], 1)):
+            return None
+        try:
+            return ops.conv2d_wino_bx3(inputs, c.packed_wino_bx3(), None if c.bias is None else c.bias.data, residual,
+                                       act_out=act_out, pool2=True)
+        except _lib.IpdmUnsupported:
+            return None
 
 
 class CRPBlock(nn.Module):
@@ -302,6 +318,9 @@ class ResidualBlock(nn.Module):
         else:
             shortcut = self.shortcut(x)
         if isinstance(self.conv2, ConvMeanPool):
+            fused = self.conv2.fused(a2, residual=shortcut, act_out=code if want_act else ops.ACT_NONE)
+            if fused is not None:                        # conv + 2x2 mean + shortcut (+ activated copy): one launch
+                return fused
             out = ops.add(shortcut, self.conv2(a2))
             return (out, ops.act(out, code)) if want_act else out
         if want_act:

@@ -247,12 +247,12 @@ def magnitude(x):
 
 
 def posterior_moment_planes(samples):
-    """samples (n, ..., H, W) complex64 -> (6, ..., H, W) float32 partial sums over the n samples:
+    """samples (n, ..., H, W) complex64 -> (6, ..., H, W) float64 partial sums over the n samples:
     sum |x|, sum |x|^2, sum angle, sum angle^2, sum Re, sum Im"""
     samples = _gpu(samples, torch.complex64, "samples")
     n = samples.shape[0]
     hw = samples[0].numel() if n else 0
-    planes = torch.empty((6,) + tuple(samples.shape[1:]), dtype=torch.float32, device=samples.device)
+    planes = torch.empty((6,) + tuple(samples.shape[1:]), dtype=torch.float64, device=samples.device)
     call("ipdm_posterior_moments_c64", _ptr(samples), _ptr(planes), n, hw, _stream())
     return planes
 
@@ -682,16 +682,21 @@ def conv_wino_bx3_supported(Cin, Cout, H, W, dilation=1):
     return bool(_lib.lib.ipdm_conv2d_wino_bx3_supported(Cin, Cout, H, W, dilation))
 
 
-def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dilation=1):
-    """3x3 convolution through the split-bf16 Winograd kernel (same output options as conv2d)"""
+def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dilation=1, pool2=False):
+    """3x3 convolution through the split-bf16 Winograd kernel (same output options as conv2d).
+    pool2: the ConvMeanPool form -- outputs (and the residual) are [B, Cout, H/2, W/2] 2x2 means of the convolution;
+    raises IpdmUnsupported where the pooled epilogue is not built (small / odd images)."""
     x = _gpu(x, torch.float32, "x")
     B, Cin, H, W = x.shape
     if U.kk != 16 or U.Cin != Cin:
         raise ValueError("conv2d_wino_bx3: weight blob does not match the input")
     Cout = U.Cout
     want_act = act_out != ACT_NONE
-    out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device) if raw else None
-    out_act = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device) if want_act else None
+    oh, ow = (H // 2, W // 2) if pool2 else (H, W)
+    if residual is not None and tuple(residual.shape) != (B, Cout, oh, ow):
+        raise ValueError(f"conv2d_wino_bx3: residual {tuple(residual.shape)} != output {(B, Cout, oh, ow)}")
+    out = torch.empty((B, Cout, oh, ow), dtype=torch.float32, device=x.device) if raw else None
+    out_act = torch.empty((B, Cout, oh, ow), dtype=torch.float32, device=x.device) if want_act else None
     if CONV_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -700,11 +705,12 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
         b1 = min(B, b0 + nb)
         call("ipdm_conv2d_wino_bx3_f32", _ptr(x[b0:b1]), _ptr(U.blob), _ptr(bias),
              _ptr(None if residual is None else residual[b0:b1]), _ptr(None if out is None else out[b0:b1]),
-             _ptr(None if out_act is None else out_act[b0:b1]), act_out, b1 - b0, Cin, Cout, H, W, dilation, _stream())
+             _ptr(None if out_act is None else out_act[b0:b1]), act_out, b1 - b0, Cin, Cout, H, W, dilation,
+             int(bool(pool2)), _stream())
     if CONV_TRACE is not None:
         e1.record()
         CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, res=residual is not None,
-                               n_out=int(raw) + int(want_act), e0=e0, e1=e1))
+                               n_out=int(raw) + int(want_act), pool2=bool(pool2), e0=e0, e1=e1))
     return (out, out_act) if want_act else out
 
 

@@ -21,24 +21,24 @@ def shard_range(total, world_size, rank):
 
 
 def moment_planes(samples):
-    """samples (n, 1, H, W) complex -> (6, 1, H, W) float32 partial sums:
+    """samples (n, 1, H, W) complex -> (6, 1, H, W) float64 partial sums:
     sum|x|, sum|x|^2, sum angle, sum angle^2, sum Re, sum Im  (helpers/metrics.py:77-92 semantics).
     GPU tensors: one kernel (ipdm_posterior_moments_c64); CPU tensors (the gloo tests): the same sums in torch."""
     if samples.is_cuda:
         from . import ops
         return ops.posterior_moment_planes(samples.to(torch.complex64).contiguous())
-    mag, ph = samples.abs().float(), samples.angle().float()
+    mag, ph = samples.abs().float().double(), samples.angle().float().double()
     return torch.stack([mag.sum(0), (mag * mag).sum(0), ph.sum(0), (ph * ph).sum(0),
-                        samples.real.float().sum(0), samples.imag.float().sum(0)])
+                        samples.real.double().sum(0), samples.imag.double().sum(0)])
 
 
 def posterior_from_moments(m, n):
-    """-> dict(mag_mean, phase_mean, mag_std, phase_std, mean) (population std, as np.std)"""
+    """-> dict(mag_mean, phase_mean, mag_std, phase_std, mean) float32 / complex64 (population std, as np.std)"""
     mag_mean, ph_mean = m[0] / n, m[2] / n
-    return dict(mag_mean=mag_mean, phase_mean=ph_mean,
-                mag_std=(m[1] / n - mag_mean ** 2).clamp_min(0).sqrt(),
-                phase_std=(m[3] / n - ph_mean ** 2).clamp_min(0).sqrt(),
-                mean=torch.complex(m[4] / n, m[5] / n))
+    return dict(mag_mean=mag_mean.float(), phase_mean=ph_mean.float(),
+                mag_std=(m[1] / n - mag_mean ** 2).clamp_min(0).sqrt().float(),
+                phase_std=(m[3] / n - ph_mean ** 2).clamp_min(0).sqrt().float(),
+                mean=torch.complex((m[4] / n).float(), (m[5] / n).float()))
 
 
 def all_reduce_posterior(local_samples, total):

@@ -773,5 +773,31 @@ def test_device_metrics_match_host_definitions(ops):
     np.testing.assert_allclose(mm, wm, atol=1e-6)
     np.testing.assert_allclose(pm, wp, atol=2e-6)
     np.testing.assert_allclose(ms, ws_, atol=2e-5)
-    np.testing.assert_allclose(ps, wps, atol=2e-4)      # E[x^2] - E[x]^2 in float32 on angles of O(pi)
+    np.testing.assert_allclose(ps, wps, atol=2e-5)      # float64 moment planes
     np.testing.assert_allclose(ops.magnitude(dev(rec)).cpu().numpy(), np.abs(rec), rtol=1e-6)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(3, 128, 256, 64, 64), (2, 32, 64, 32, 96), (2, 64, 128, 40, 36)])
+def test_conv_wino_bx3_pooled_epilogue(ops, B, Cin, Cout, H, W):
+    """ConvMeanPool in one launch (the Winograd output tile is the 2x2 pooling window): conv + bias -> 2x2 mean -> + pooled
+    residual -> (ELU copy), against float64 torch, same 4e-6 bound as the unpooled kernel"""
+    gen = torch.Generator().manual_seed(41)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=gen)
+    r = torch.randn(B, Cout, H // 2, W // 2, generator=gen)
+    want = torch.nn.functional.avg_pool2d(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1), 2) + r.double()
+    U = ops.conv_wino_bx3_weight(w.cuda())
+    out, out_act = ops.conv2d_wino_bx3(x.cuda(), U, b.cuda(), r.cuda(), act_out=ops.ACT_ELU, pool2=True)
+    assert out.shape == (B, Cout, H // 2, W // 2)
+    scale = float(want.abs().max())
+    assert float((out.cpu().double() - want).abs().max()) < 4e-6 * scale
+    assert float((out_act.cpu().double() - torch.nn.functional.elu(want)).abs().max()) < 4e-6 * scale
+    # and exactly the unfused chain's value up to the summation order of the four window elements
+    full = ops.conv2d_wino_bx3(x.cuda(), U, b.cuda())
+    chain = ops.add(ops.meanpool2(full), r.cuda())
+    assert float((chain - out).abs().max()) < 2e-6 * scale
+    only_act = ops.conv2d_wino_bx3(x.cuda(), U, b.cuda(), r.cuda(), act_out=ops.ACT_ELU, raw=False, pool2=True)
+    assert only_act[0] is None and torch.equal(only_act[1], out_act)
+    with pytest.raises(Exception):
+        ops.conv2d_wino_bx3(x.cuda()[:, :, :16, :16].contiguous(), U, b.cuda(), pool2=True)     # small-image kernels: unsupported
