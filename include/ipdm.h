@@ -113,6 +113,8 @@ typedef struct ipdm_sched_t {
   float coef;        /* proximal coefficient (see ipdm_sense_l2prox_f32)    */
   float sigma;       /* current noise level (informational)                 */
   int64_t step_id;   /* global iteration counter: Philox key                */
+  float seg_scale;   /* segmentation-likelihood weight lh_weight / sigma (ALD_optimizers.py:283) */
+  float reserved;    /* keeps the struct 32 bytes                            */
 } ipdm_sched_t;
 
 /* One fused Annealed-Langevin iteration tail for the SENSE sampler (reference:
@@ -308,6 +310,29 @@ int ipdm_conv2d_wino_bx3_supported(int Cin, int Cout, int H, int W, int dilation
 int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
                              float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
                              int pool2, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Segmentation-likelihood guidance (reference: ncsn/models/__init__.py:197-215 compute_seg_grad through a MONAI UNet --
+ * stride-2 Convolution / transposed Convolution blocks with InstanceNorm + PReLU --, ALD_optimizers.py:272-286).
+ * The strided (transposed) convolutions and their input-gradients run on ipdm_conv2d_bx3_f32 between these:
+ * ---------------------------------------------------------------------------------------------- */
+
+/* out [planes][2H][2W]: out[2i][2j] = x[i][j], zero elsewhere */
+int ipdm_zero_insert2_f32(const float* x, float* out, int planes, int H, int W, void* stream);
+/* out [planes][H/2][W/2] = x[2i][2j] */
+int ipdm_subsample2_f32(const float* x, float* out, int planes, int H, int W, void* stream);
+/* per-plane InstanceNorm (biased variance, eps, no affine) + PReLU with one slope (slope NULL: identity):
+ * xhat = (x - mean) * rstd, y = prelu(xhat); rstd [planes] and xhat are what the backward needs */
+int ipdm_in_prelu_fwd_f32(const float* x, const float* slope, float* xhat, float* y, float* rstd, int planes, int HW,
+                          float eps, void* stream);
+/* input-gradient of ipdm_in_prelu_fwd_f32 */
+int ipdm_in_prelu_bwd_f32(const float* gy, const float* xhat, const float* rstd, const float* slope, float* gx, int planes,
+                          int HW, void* stream);
+/* g = d/dlogits sum log softmax(logits)[label]: g[b][c][p] = [c == label[b][p]] - softmax_c; logits [B][C][HW], label int64 */
+int ipdm_seg_loglh_grad_f32(const float* logits, const int64_t* label, float* g, int B, int C, int64_t HW, void* stream);
+/* y += scale * x (* mask[i % mask_period], the "FG" mode); scale = dev_sched->seg_scale when dev_sched is non-NULL */
+int ipdm_axpy_sched_f32(float* y, const float* x, const int64_t* mask, int64_t mask_period, const ipdm_sched_t* dev_sched,
+                        float scale, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * On-device reporting (reference: helpers/metrics.py:21-102, helpers/visualizations.py:93,117,121).  Deterministic

@@ -19,8 +19,9 @@ Extra, optional call kwargs (none changes the defaults' semantics):
     use_graph                  capture/replay one iteration as a hipGraph
 Differences kept on purpose: the reference's per-step ``print(max, min)`` syncs and PNG dumps are gone;
 ``torch.set_grad_enabled(False)`` is scoped to the call instead of leaking globally.
-Segmentation guidance (``adjust_grad`` -> compute_seg_grad) is a "next" row: a ``seg`` net
-is honoured only where its weight is zero (``seg_start_time == 1``), anything else raises.
+Segmentation guidance (``adjust_grad`` -> compute_seg_grad, :272-286): with a ``seg`` network that offers the fused
+forward + input-gradient chain (``seg_unet.UNet.loglh_grad``) the iteration adds ``seg_grad / sigma * lh_weight`` to both
+score planes before the Langevin update (skipped altogether when every weight is zero, ``seg_start_time == 1``).
 """
 import abc
 
@@ -34,7 +35,7 @@ from ...helpers.utils import data_transform, reshape_temporal_dim
 from ..linear_transforms.finite_diff import FiniteDiff
 
 SCHED_DTYPE = np.dtype([("step", "<f4"), ("noise_scale", "<f4"), ("coef", "<f4"), ("sigma", "<f4"),
-                        ("step_id", "<i8")])
+                        ("step_id", "<i8"), ("seg_scale", "<f4"), ("reserved", "<f4")])     # = ipdm_sched_t, 32 bytes
 
 
 def get_lh_weights(sigmas, start_time, curve_type="linear"):
@@ -162,6 +163,11 @@ class ALDInvSegProximalRealImag(ALDOptimizer):
     def _iteration(self, st):
         grad = self.scorenet(st["x"], st["labels"])
         B = st["B"]
+        if st.get("seg_label") is not None:
+            # adjust_grad (:272-286): grad + compute_seg_grad(seg, x, label, seg_mode) / sigma * lh_weight on the real and
+            # on the imaginary plane (same label); the scalar lh_weight / sigma of this level sits in the device schedule
+            gseg = self.seg.loglh_grad(st["x"], st["seg_label"], st["seg_mode"])
+            ops.axpy_sched(grad, gseg, dev_sched=st["sched_dev"])
         if st["sc_mode"] is None:            # multi-coil SENSE + L2Penalty
             ops.ald_sense_step(st["x"][:B], st["x"][B:], grad[:B], grad[B:], st["y"], st["sens"], st["mask"], st["work"],
                                noise_re=st["noise_re"], noise_im=st["noise_im"], seed=st["seed"],
@@ -174,9 +180,10 @@ class ALDInvSegProximalRealImag(ALDOptimizer):
     def _check_fast_path(self, kwargs):
         """-> sc_mode: None for SENSE + L2Penalty, the ipdm_singlecoil_prox_f32 mode for the single-coil operators
         (the reference's acdc_inv_seg_sampling_keep_center_prox_real_imag.py:79-89 / cine_inv_sampling_...:78-88)"""
-        if self.seg is not None and bool((self.lh_weights != 0).any()):
-            raise NotImplementedError("segmentation-likelihood guidance with non-zero weight is not built yet "
-                                      "(SURVEY.md 8f rank 1); use seg_start_time=1 or seg=None")
+        if self._seg_active() and not hasattr(self.seg, "loglh_grad"):
+            raise NotImplementedError("segmentation-likelihood guidance needs a network with the fused forward + input-gradient "
+                                      f"chain (ncsn.models.seg_unet.UNet.loglh_grad); got {type(self.seg).__name__}: there is "
+                                      "no autograd on the HIP path")
         if isinstance(self.linear_tfm, SENSE):
             if isinstance(self.proximal, L2Penalty):
                 return None
@@ -190,6 +197,9 @@ class ALDInvSegProximalRealImag(ALDOptimizer):
             raise TypeError("Constrained.__call__() takes 4 positional arguments but 5 were given")
         raise NotImplementedError(f"no fused iteration for {type(self.proximal).__name__} + "
                                   f"{type(self.linear_tfm).__name__}")
+
+    def _seg_active(self):
+        return self.seg is not None and bool((self.lh_weights != 0).any())
 
     @torch.no_grad()
     def __call__(self, **kwargs):
@@ -227,6 +237,12 @@ class ALDInvSegProximalRealImag(ALDOptimizer):
         if noise_fn is not None:
             st["noise_re"] = torch.empty(B, 1, H, W, device=dev)
             st["noise_im"] = torch.empty(B, 1, H, W, device=dev)
+        if self._seg_active():
+            label = kwargs["label"].to(dev, torch.int64)
+            if label.shape[0] != B:
+                label = label.expand(B, *label.shape[1:])
+            st["seg_label"] = torch.cat([label, label], dim=0).contiguous()   # real planes | imaginary planes
+            st["seg_mode"] = kwargs.get("seg_mode", "full")
         # all per-step scalars for the run, uploaded once; each step copies its 24-byte record on-stream
         n_it = (lv1 - lv0) * n_steps_each
         table = np.zeros(n_it, dtype=SCHED_DTYPE)
@@ -234,6 +250,7 @@ class ALDInvSegProximalRealImag(ALDOptimizer):
         table["step"], table["noise_scale"] = steps.numpy()[lv], noise_scales.numpy()[lv]
         table["coef"], table["sigma"] = coef, sigmas.detach().cpu().numpy()[lv]
         table["step_id"] = lv0 * n_steps_each + np.arange(n_it)
+        table["seg_scale"] = (self.lh_weights.detach().cpu().float() / sigmas.detach().cpu().float()).numpy()[lv]
         table_dev = torch.from_numpy(table.view(np.uint8).reshape(n_it, -1).copy()).to(dev)
         label_table = torch.from_numpy(np.repeat(lv[:, None], 2 * B, axis=1)).to(dev)
 

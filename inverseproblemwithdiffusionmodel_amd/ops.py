@@ -238,6 +238,75 @@ def philox_normal(shape, device, seed=0, sample_offset=0, step_id=0, plane=0):
     return out
 
 
+# ---- segmentation-likelihood guidance glue ----------------------------------------------------------
+def zero_insert2(x):
+    """(..., H, W) -> (..., 2H, 2W): x at the even positions, zeros elsewhere"""
+    x = _gpu(x, torch.float32, "x")
+    H, W = x.shape[-2:]
+    out = torch.empty(tuple(x.shape[:-2]) + (2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    call("ipdm_zero_insert2_f32", _ptr(x), _ptr(out), x.numel() // (H * W), H, W, _stream())
+    return out
+
+
+def subsample2(x):
+    """(..., H, W) -> (..., H/2, W/2): the even positions"""
+    x = _gpu(x, torch.float32, "x")
+    H, W = x.shape[-2:]
+    out = torch.empty(tuple(x.shape[:-2]) + (H // 2, W // 2), dtype=torch.float32, device=x.device)
+    call("ipdm_subsample2_f32", _ptr(x), _ptr(out), x.numel() // (H * W), H, W, _stream())
+    return out
+
+
+def in_prelu_fwd(x, slope, eps=1e-5):
+    """InstanceNorm (no affine) + PReLU(one slope) on (B, C, H, W) -> (xhat, y, rstd (B*C,))"""
+    x = _gpu(x, torch.float32, "x")
+    B, C = x.shape[:2]
+    hw = x.numel() // max(B * C, 1)
+    xhat, y = torch.empty_like(x), torch.empty_like(x)
+    rstd = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    call("ipdm_in_prelu_fwd_f32", _ptr(x), _ptr(slope), _ptr(xhat), _ptr(y), _ptr(rstd), B * C, hw, float(eps), _stream())
+    return xhat, y, rstd
+
+
+def in_prelu_bwd(gy, xhat, rstd, slope):
+    gy = _gpu(gy, torch.float32, "gy")
+    B, C = gy.shape[:2]
+    gx = torch.empty_like(gy)
+    call("ipdm_in_prelu_bwd_f32", _ptr(gy), _ptr(xhat), _ptr(rstd), _ptr(slope), _ptr(gx), B * C, gy.numel() // max(B * C, 1),
+         _stream())
+    return gx
+
+
+def seg_loglh_grad(logits, label):
+    """d/dlogits of sum log softmax(logits, dim=1)[label]: logits (B, C, H, W) f32, label (B, 1, H, W) int64"""
+    logits = _gpu(logits, torch.float32, "logits")
+    label = _gpu(label, torch.int64, "label")
+    B, C = logits.shape[:2]
+    hw = logits.numel() // max(B * C, 1)
+    if label.numel() != B * hw:
+        raise ValueError(f"seg_loglh_grad: label {tuple(label.shape)} does not match logits {tuple(logits.shape)}")
+    g = torch.empty_like(logits)
+    call("ipdm_seg_loglh_grad_f32", _ptr(logits), _ptr(label), _ptr(g), B, C, hw, _stream())
+    return g
+
+
+def axpy_sched(y, x, scale=0.0, dev_sched=None, mask=None):
+    """y += scale * x (* mask, broadcast over y's leading copies) in place; dev_sched: the device ipdm_sched_t whose
+    seg_scale replaces `scale` (graph replay)"""
+    _inplace_operand(y, torch.float32, "y")
+    _inplace_operand(x, torch.float32, "x")
+    if x.numel() != y.numel():
+        raise ValueError("axpy_sched: x does not match y")
+    period = 0
+    if mask is not None:
+        _inplace_operand(mask, torch.int64, "mask")
+        period = mask.numel()
+        if y.numel() % period:
+            raise ValueError("axpy_sched: mask does not tile y")
+    call("ipdm_axpy_sched_f32", _ptr(y), _ptr(x), _ptr(mask), period, _ptr(dev_sched), float(scale), y.numel(), _stream())
+    return y
+
+
 # ---- on-device reporting ------------------------------------------------------------------------
 def magnitude(x):
     x = _gpu(x, torch.complex64, "x")

@@ -4,8 +4,8 @@ Reference anchors (ncsn/models/ALD_optimizers.py):
   ald_unconditional      :66-137   (ALDOptimizer.__call__ / ALDUnconditionalSampler)
   ald_sense_real_imag    :172-270  (ALDInvSegProximalRealImag.__call__) with
                          :288-327  (post_processing -> proximal(x, y, step_lr*lr_scaled, 1.))
-Segmentation guidance is taken at weight 0 (seg_start_time = 1, ALD_optimizers.py:27-28), i.e. the
-score is used unmodified.  Noise is INJECTED (noise_fn) because the reference draws it on the
+Segmentation guidance: off (weight 0, seg_start_time = 1, ALD_optimizers.py:27-28) unless a seg_grad_fn and the
+lh_weights ramp are passed.  Noise is INJECTED (noise_fn) because the reference draws it on the
 compute device.
 """
 import numpy as np
@@ -37,7 +37,7 @@ def ald_unconditional(score_fn, sigmas, x0, step_lr, n_steps_each, denoise, nois
 
 
 def ald_sense_real_imag(score_fn, sigmas, measurement, maps, mask, step_lr, n_steps_each, lr_scaled,
-                        denoise, noise_fn, n_levels=None, start_level=0, x_init=None):
+                        denoise, noise_fn, n_levels=None, start_level=0, x_init=None, seg_grad_fn=None, lh_weights=None):
     """measurement (n_coils, B, 1, H, W) complex64 numpy.  Returns complex64 numpy (B, 1, H, W).
     n_levels / start_level / x_init let the CPU baseline time a bounded slice of the schedule."""
     sigmas = torch.as_tensor(sigmas)
@@ -53,6 +53,9 @@ def ald_sense_real_imag(score_fn, sigmas, measurement, maps, mask, step_lr, n_st
         for _ in range(n_steps_each):
             g_re = score_fn(x_re, labels)
             g_im = score_fn(x_im, labels)
+            if seg_grad_fn is not None:          # adjust_grad (:272-286): grad + grad_log_lh_seg / sigma * lamda
+                g_re = g_re + seg_grad_fn(x_re) / sigma * lh_weights[c]
+                g_im = g_im + seg_grad_fn(x_im) / sigma * lh_weights[c]
             x_re = x_re + step * g_re + noise_fn(x_re) * torch.sqrt(step * 2)
             x_im = x_im + step * g_im + noise_fn(x_im) * torch.sqrt(step * 2)
             z = (x_re.numpy() + 1j * x_im.numpy()).astype(np.complex64)

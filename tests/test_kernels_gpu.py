@@ -302,7 +302,7 @@ def test_large_image_kspace_ops_vs_oracle(ops, H, W):
     work = ops.sense_workspace(B, n, H, W, "cuda")
     assert work.numel() * 4 == n * B * H * W * 8
     x_re, x_im = dev(x.real), dev(x.imag)
-    sched = np.zeros(1, dtype=[("step", "f4"), ("ns", "f4"), ("coef", "f4"), ("sigma", "f4"), ("id", "i8")])
+    sched = np.zeros(1, dtype=[("step", "f4"), ("ns", "f4"), ("coef", "f4"), ("sigma", "f4"), ("id", "i8"), ("seg", "f4"), ("rsv", "f4")])
     sched["step"], sched["ns"], sched["coef"], sched["id"] = step, ns, coef, 5
     ops.ald_sense_step(x_re, x_im, dev(g[0]), dev(g[1]), dev(y), sens, m8, work, noise_re=dev(nz[0]), noise_im=dev(nz[1]),
                        dev_sched=dev(sched.view(np.uint8)))
@@ -406,7 +406,7 @@ def test_ald_sense_step_matches_oracle(ops):
     assert np.abs(want - z).max() > 1e-3                         # the data term is visible in this test
     np.testing.assert_allclose(got, want, atol=5e-6)
     # device-resident schedule struct gives the same result
-    sched = np.zeros(1, dtype=[("step", "f4"), ("ns", "f4"), ("coef", "f4"), ("sigma", "f4"), ("id", "i8")])
+    sched = np.zeros(1, dtype=[("step", "f4"), ("ns", "f4"), ("coef", "f4"), ("sigma", "f4"), ("id", "i8"), ("seg", "f4"), ("rsv", "f4")])
     sched["step"], sched["ns"], sched["coef"] = step, ns, coef
     x_re2, x_im2 = dev(x.real), dev(x.imag)
     ops.ald_sense_step(x_re2, x_im2, dev(g[0]), dev(g[1]), dev(y), dev(maps.astype(np.float32)),
