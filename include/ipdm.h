@@ -341,8 +341,9 @@ int ipdm_axpy_sched_f32(float* y, const float* x, const int64_t* mask, int64_t m
 
 /* out[i] = |x[i]| */
 int ipdm_magnitude_c64(const float* x /* n complex64 */, float* out, int64_t n, void* stream);
-/* samples [n_samples][HW] complex64 -> planes [6][HW] float64: sum |x|, sum |x|^2, sum angle, sum angle^2, sum Re,
- * sum Im over the samples (compute_mean_and_std, helpers/metrics.py:77-92, as partial sums a shard can all-reduce) */
+/* samples [n_samples][HW] complex64 -> planes [7][HW] float64: sum |x|, sum |x|^2, sum angle, sum angle^2, sum Re,
+ * sum Im, sum |angle| over the samples (compute_mean_and_std, helpers/metrics.py:77-92, as partial sums a shard can
+ * all-reduce; the reference's phase std is np.std(np.abs(angle)), hence the last plane) */
 int ipdm_posterior_moments_c64(const float* samples, double* planes, int n_samples, int64_t HW, void* stream);
 /* NRMSE_wrapper (helpers/metrics.py:70-74): skimage normalized_root_mse(img, ref, "euclidean") = ||img - ref|| / ||img||,
  * img [n_images][elems]; ref [n_images][elems] or one [elems] image shared by all (ref_broadcast) */

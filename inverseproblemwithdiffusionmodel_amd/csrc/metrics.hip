@@ -26,20 +26,21 @@ __global__ __launch_bounds__(256) void magnitude_kernel(const float2* __restrict
   }
 }
 
-// samples [n][HW] complex64 -> planes [6][HW] float64: sum |x|, sum |x|^2, sum angle, sum angle^2, sum Re, sum Im
+// samples [n][HW] complex64 -> planes [7][HW] float64: sum |x|, sum |x|^2, sum angle, sum angle^2, sum Re, sum Im,
+// sum |angle| -- the reference's phase "std" is np.std(np.abs(angle)) (helpers/metrics.py:82-83 applied to the phase stack)
 // (sample order 0..n-1 per pixel: the partial sums of a shard are what sharding.all_reduce_posterior adds up; float64
 //  sums, because std = sqrt(E[x^2] - E[x]^2) of angles of O(pi) loses 1e-4 in float32)
 __global__ __launch_bounds__(256) void posterior_moments_kernel(const float2* __restrict__ s, double* __restrict__ planes,
                                                                 int n, int64_t HW) {
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < HW; p += (int64_t)gridDim.x * 256) {
-    double m1 = 0, m2 = 0, a1 = 0, a2 = 0, re = 0, im = 0;
+    double m1 = 0, m2 = 0, a1 = 0, a2 = 0, re = 0, im = 0, aa = 0;
     for (int k = 0; k < n; ++k) {
       const float2 v = s[(size_t)k * HW + p];
       const double mag = hypotf(v.x, v.y), ang = atan2f(v.y, v.x);      // float32 |x| and angle, as numpy on complex64
-      m1 += mag; m2 += mag * mag; a1 += ang; a2 += ang * ang; re += v.x; im += v.y;
+      m1 += mag; m2 += mag * mag; a1 += ang; a2 += ang * ang; re += v.x; im += v.y; aa += fabs(ang);
     }
     planes[p] = m1; planes[HW + p] = m2; planes[2 * HW + p] = a1; planes[3 * HW + p] = a2;
-    planes[4 * HW + p] = re; planes[5 * HW + p] = im;
+    planes[4 * HW + p] = re; planes[5 * HW + p] = im; planes[6 * HW + p] = aa;
   }
 }
 

@@ -7,12 +7,18 @@ import torch
 
 from ..ncsn.models.ncsnv2 import NCSNv2, NCSNv2Deeper, NCSNv2Deepest
 from ..ncsn.models.ncsn3d import NCSN3DShallow
+from ..ncsn.models.seg_unet import UNet
+
+# ncsn/configs/general_config.yml:1-6 of the reference ("Seg": the MONAI UNet arguments)
+GENERAL_CONFIG = {"Seg": dict(spatial_dims=2, in_channels=1, out_channels=2, channels=[64, 128, 256, 512, 1024],
+                              strides=[2, 2, 2, 2])}
 
 TASK_NAME_TO_MODEL_CTOR = {
     "Diffusion": NCSNv2Deepest,
     "Diffusion3D": NCSN3DShallow,
     "DiffusionShallow": NCSNv2,
     "DiffusionDeeper": NCSNv2Deeper,
+    "Seg": UNet,
 }
 
 
@@ -44,7 +50,22 @@ def reload_model(task_name, ds_name, mode="real-valued", ckpt_path=None, device=
     synthetic weights of synthetic.py (no checkpoints ship with the reference)"""
     from .load_data import load_config
     from ..synthetic import synth_state_dict
-    assert task_name in TASK_NAME_TO_MODEL_CTOR, f"{task_name}: only the score networks are built (no Seg / Clf)"
+    assert task_name in TASK_NAME_TO_MODEL_CTOR, f"{task_name}: the score networks and the segmentation UNet are built (no Clf)"
+    if task_name == "Seg":
+        # helpers/load_model.py:140-141: UNet(**general_config["Seg"]); Lightning TrainSeg checkpoints carry the weights
+        # under 'model.' + MONAI's names, which extract_ema_state_dict / collate_state_dict strip
+        if device is None:
+            device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+        model = UNet(**GENERAL_CONFIG["Seg"])
+        if ckpt_path is not None:
+            load_scorenet_weights(model, ckpt_path)
+        else:
+            sd = synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=0)
+            for k in sd:
+                if k.endswith("adn.A.weight"):
+                    sd[k] = torch.full_like(sd[k], 0.25)         # PReLU slope at its init value
+            model.load_state_dict(sd, strict=False)
+        return model.to(device).eval()
     ds_cfg = ds_name + "_1D" if task_name == "Diffusion3D" and not ds_name.endswith("_1D") else ds_name
     config = load_config(ds_cfg, mode, device)
     model = TASK_NAME_TO_MODEL_CTOR[task_name](config)

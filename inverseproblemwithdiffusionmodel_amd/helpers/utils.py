@@ -61,3 +61,17 @@ def vis_images(*args, **kwargs):
 
 def vis_multi_channel_signal(*args, **kwargs):
     return None
+
+
+def undersample_seg_mask(label: torch.Tensor, fraction=1., seed=None):
+    """keep a random `fraction` of the labelled pixels (mirror of helpers/utils.py:314-327; same torch RNG calls)"""
+    assert 0. <= fraction <= 1.
+    if seed is not None:
+        torch.random.manual_seed(seed)
+    non_zeros = torch.nonzero(label.cpu(), as_tuple=True)
+    num_samples = max(1, int(non_zeros[0].shape[0] * fraction))
+    sample_indices = torch.randperm(non_zeros[0].shape[0])[:num_samples]
+    indices = [ind[sample_indices] for ind in non_zeros]
+    label_out = torch.zeros_like(label.cpu())
+    label_out[indices] = 1
+    return label_out.to(label.device)

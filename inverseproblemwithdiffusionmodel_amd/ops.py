@@ -316,12 +316,12 @@ def magnitude(x):
 
 
 def posterior_moment_planes(samples):
-    """samples (n, ..., H, W) complex64 -> (6, ..., H, W) float64 partial sums over the n samples:
-    sum |x|, sum |x|^2, sum angle, sum angle^2, sum Re, sum Im"""
+    """samples (n, ..., H, W) complex64 -> (7, ..., H, W) float64 partial sums over the n samples:
+    sum |x|, sum |x|^2, sum angle, sum angle^2, sum Re, sum Im, sum |angle|"""
     samples = _gpu(samples, torch.complex64, "samples")
     n = samples.shape[0]
     hw = samples[0].numel() if n else 0
-    planes = torch.empty((6,) + tuple(samples.shape[1:]), dtype=torch.float64, device=samples.device)
+    planes = torch.empty((7,) + tuple(samples.shape[1:]), dtype=torch.float64, device=samples.device)
     call("ipdm_posterior_moments_c64", _ptr(samples), _ptr(planes), n, hw, _stream())
     return planes
 

@@ -35,6 +35,7 @@ def ssim(a, b, data_range=None, win=7, K1=0.01, K2=0.03):
 
 
 def posterior_moments(samples):
-    """helpers/metrics.py:77-92 for complex input: mean/std of |x| and of angle(x) over samples."""
+    """helpers/metrics.py:77-92 for complex input: compute_mean_and_std on |x| and on angle(x), each through the
+    real-valued branch `np.mean(imgs), np.std(np.abs(imgs))` (:82-83) -- so the phase "std" is the std of |angle|."""
     mag, ph = np.abs(samples), np.angle(samples)
-    return mag.mean(0), ph.mean(0), mag.std(0), ph.std(0)
+    return mag.mean(0), ph.mean(0), np.abs(mag).std(0), np.abs(ph).std(0)

@@ -20,7 +20,7 @@ if __name__ == '__main__':
     parser.add_argument("--R", type=int, default=40)
     parser.add_argument("--center_lines_frac", type=float, default=1 / 4)
     parser.add_argument("--seed", type=int, default=0)
-    parser.add_argument("--seg_start_time", type=float, default=1.)      # 1 = segmentation guidance off (not built)
+    parser.add_argument("--seg_start_time", type=float, default=0.)      # the reference's default: guidance ramps in from level 0
     parser.add_argument("--seg_step_type", default="linear")
     parser.add_argument("--lamda", type=float, default=0.1)
     parser.add_argument("--step_lr", type=float, default=0.0000009)
@@ -38,8 +38,14 @@ if __name__ == '__main__':
     parser.add_argument("--image_size", type=int, default=128)
     parser.add_argument("--ckpt", default=None, help="Lightning .ckpt of the reference (EMA weights); default: synthetic")
     parser.add_argument("--n_levels", type=int, default=None, help="run only the first n noise levels")
+    parser.add_argument("--seg_ckpt", default=None, help="Lightning TrainSeg .ckpt (MONAI UNet weights) for the guidance")
+    parser.add_argument("--seg_synthetic", action="store_true",
+                        help="run the guidance with seeded random UNet weights (exercises the path; not meaningful imaging)")
     args_dict = vars(parser.parse_args())
-    assert args_dict["seg_start_time"] >= 1., "segmentation guidance is outside this build (SURVEY.md 8: 'next')"
+    if args_dict["seg_start_time"] < 1. and not (args_dict["seg_ckpt"] or args_dict["seg_synthetic"]):
+        print("no --seg_ckpt: segmentation-likelihood guidance needs trained UNet weights -> running with seg_start_time = 1 "
+              "(guidance off); pass --seg_synthetic to exercise the path with random weights")
+        args_dict["seg_start_time"] = 1.
 
     world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -62,13 +68,25 @@ if __name__ == '__main__':
         load_scorenet_weights(scorenet, args_dict["ckpt"])
     prob = engine.build_problem(device, n_local, R=args_dict["R"], H=H, W=H, num_sens=args_dict["num_sens"],
                                 seed=args_dict["seed"], scorenet=scorenet, cfg=cfg, lr_scaled=args_dict["lr_scaled"])
+    label = None
+    if args_dict["seg_start_time"] < 1.:
+        from inverseproblemwithdiffusionmodel_amd.helpers.load_model import reload_model
+        from inverseproblemwithdiffusionmodel_amd.helpers.utils import undersample_seg_mask
+        from inverseproblemwithdiffusionmodel_amd.ncsn.models.ALD_optimizers import ALDInvSegProximalRealImag
+        seg = reload_model("Seg", "ACDC", ckpt_path=args_dict["seg_ckpt"], device=device)
+        label = (prob.image.abs() > 0.5).long()                       # synthetic stand-in for the myocardium label
+        label = undersample_seg_mask(label, args_dict["seg_fraction"], seed=args_dict["seed"])
+        s0 = prob.sampler
+        prob.sampler = ALDInvSegProximalRealImag(s0.proximal, args_dict["seg_start_time"], args_dict["seg_step_type"],
+                                                 s0.x_mod_shape, s0.scorenet, s0.sigmas, s0.params, s0.config, s0.measurement,
+                                                 s0.linear_tfm, seg=seg, device=device)
     save_dir = args_dict["save_dir"]
     if rank == 0:
         os.makedirs(save_dir, exist_ok=True)
     direct_recons = prob.op.conj_op(prob.measurement[:, :1])
 
     t0 = time.time()
-    kw = dict(prob.call_kwargs, lamda=args_dict["lamda"], save_dir=save_dir, seg_mode=args_dict["seg_mode"],
+    kw = dict(prob.call_kwargs, label=label, lamda=args_dict["lamda"], save_dir=save_dir, seg_mode=args_dict["seg_mode"],
               seed=args_dict["seed"], sample_offset=lo, n_levels=args_dict["n_levels"], verbose=(rank == 0))
     img_out = prob.sampler(**kw)[0][: hi - lo]
     torch.cuda.synchronize()

@@ -1,5 +1,5 @@
 """The N > 1 path on CPU: world_size-2 gloo processes each own a block of the posterior samples and the
-single collective of the path (one all-reduce of six moment planes) reproduces the single-process posterior."""
+single collective of the path (one all-reduce of seven moment planes) reproduces the single-process posterior."""
 import os
 import socket
 
