@@ -425,11 +425,13 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
 // channel tiles of a pixel tile meet in that XCD's L2) and its workgroups stride through it.
 // TX x TY tiles per workgroup: 16 x 4 (8 x 32 output pixels) for wide images, 8 x 8 (16 x 16) for 16-pixel images, whose
 // workgroups are dealt channel-tile-major (CO_MAJOR: an XCD keeps ONE channel tile's 3 MiB of Winograd weights in L2).
+// POOL: the ConvMeanPool epilogue (2x2 mean of every output tile) as its own instantiation, so that the unpooled kernel's
+// register allocation is exactly what it was (a run-time branch cost it four spilled registers and ~7 % more VALU).
 // DMA4 (W % 4 == 0, 16-byte aligned tensor): the raw region is fetched as 16-byte quads aligned to multiples of four
 // pixels (a quad is then entirely inside or entirely outside the image, so the range check still pads), 25-27
 // wave-instructions per chunk and workgroup instead of 96 -- an LDS-DMA instruction costs ~100 issue cycles next to
 // MFMAs, whatever its width.
-template <int TX, int TY, bool CO_MAJOR, bool DMA4>
+template <int TX, int TY, bool CO_MAJOR, bool DMA4, bool POOL = false>
 __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int total_tiles) {
   constexpr int QC = TX / 2 + 2, RC4 = 4 * QC;               // quads / floats per raw row (x0-4 .. x0+2TX+3)
   constexpr int QN = (2 * TY + 2) * QC;                       // quads per channel
@@ -721,7 +723,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
             tt[1][qq] = m[1 * 4 + qq] - m[2 * 4 + qq] - m[3 * 4 + qq];
           }
           const float bias = a.bias ? a.bias[co] : 0.f;
-          if (a.pool2) {
+          if constexpr (POOL) {
             // ConvMeanPool: (y[::2,::2] + y[1::2,::2] + y[::2,1::2] + y[1::2,1::2]) / 4 in the reference's order; the
             // output tile IS the 2x2 pooling window, so the full-resolution result is never written
             const float y00 = tt[0][0] + tt[0][1] + tt[0][2] + bias, y01 = tt[0][1] - tt[0][2] - tt[0][3] + bias;
@@ -1168,7 +1170,9 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
                              reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, false>),
                              reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, false>),
                              reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, true>),
-                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, true>)};
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, true>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, false, true>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, true, true>)};
     for (const void* k : kernels) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS_BYTES);
       if (e != hipSuccess) return (int)e;
@@ -1228,7 +1232,11 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
   } else if (small) {
     hipLaunchKernelGGL(conv_wino_bx3_kernel<true>, dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
   } else if (wino_persist() && a.Cin >= 2 * X_KC) {
-    if (dma4)
+    if (a.pool2 && dma4)
+      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false, true, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+    else if (a.pool2)
+      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false, false, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+    else if (dma4)
       hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
     else
       hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false, false>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);

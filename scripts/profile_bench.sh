@@ -11,6 +11,6 @@ cd "$ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o "$TAG" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-alt --no-full-batch > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
 STATS=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
 echo "stats file: $STATS"
-head -40 "$STATS" > "$ROOT/profiles/${TAG}_kernel_stats.csv"
-cp "$OUT/bench.json" "$ROOT/profiles/${TAG}_bench.json"
-cat "$ROOT/profiles/${TAG}_kernel_stats.csv" | cut -c1-200 | head -30
+head -40 "$STATS" > "$OUT/${TAG}_kernel_stats_top.csv"
+
+cat "$OUT/${TAG}_kernel_stats_top.csv" | cut -c1-200 | head -30
