@@ -319,8 +319,8 @@ int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const float* bias, c
 
 /* out [planes][2H][2W]: out[2i][2j] = x[i][j], zero elsewhere */
 int ipdm_zero_insert2_f32(const float* x, float* out, int planes, int H, int W, void* stream);
-/* out [planes][H/2][W/2] = x[2i][2j] */
-int ipdm_subsample2_f32(const float* x, float* out, int planes, int H, int W, void* stream);
+/* out [planes][Ho][Wo] = x[2i + oy][2j + ox]: a stride-2 convolution is the stride-1 one sampled at (oy, ox) + 2(i, j) */
+int ipdm_subsample2_f32(const float* x, float* out, int planes, int H, int W, int oy, int ox, int Ho, int Wo, void* stream);
 /* per-plane InstanceNorm (biased variance, eps, no affine) + PReLU with one slope (slope NULL: identity):
  * xhat = (x - mean) * rstd, y = prelu(xhat); rstd [planes] and xhat are what the backward needs */
 int ipdm_in_prelu_fwd_f32(const float* x, const float* slope, float* xhat, float* y, float* rstd, int planes, int HW,

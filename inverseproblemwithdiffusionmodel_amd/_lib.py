@@ -75,7 +75,7 @@ SIGNATURES = {
     "ipdm_conv2d_wino_bx3_supported": [c_int, c_int, c_int, c_int, c_int],
     "ipdm_conv2d_wino_bx3_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "ipdm_zero_insert2_f32": [P, P, c_int, c_int, c_int, P],
-    "ipdm_subsample2_f32": [P, P, c_int, c_int, c_int, P],
+    "ipdm_subsample2_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "ipdm_in_prelu_fwd_f32": [P, P, P, P, P, c_int, c_int, c_float, P],
     "ipdm_in_prelu_bwd_f32": [P, P, P, P, P, c_int, c_int, P],
     "ipdm_seg_loglh_grad_f32": [P, P, P, c_int, c_int, c_int64, P],

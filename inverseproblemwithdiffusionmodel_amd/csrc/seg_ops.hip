@@ -33,15 +33,15 @@ __global__ __launch_bounds__(256) void zero_insert2_kernel(const float* __restri
   }
 }
 
-// out [P][H/2][W/2] = x[2i][2j]
+// out [P][Ho][Wo] = x[2i + oy][2j + ox]     (x [P][H][W]; the caller guarantees 2(Ho-1)+oy < H, 2(Wo-1)+ox < W)
 __global__ __launch_bounds__(256) void subsample2_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n_out,
-                                                         int Ho, int Wo) {
+                                                         int H, int W, int Ho, int Wo, int oy, int ox) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % Wo);
     const int64_t t = i / Wo;
     const int r = (int)(t % Ho);
     const int64_t p = t / Ho;
-    out[i] = x[(p * (2 * Ho) + 2 * r) * (int64_t)(2 * Wo) + 2 * c];
+    out[i] = x[(p * H + 2 * r + oy) * (int64_t)W + 2 * c + ox];
   }
 }
 
@@ -135,13 +135,15 @@ extern "C" int ipdm_zero_insert2_f32(const float* x, float* out, int planes, int
   return ipdm_launch_status();
 }
 
-extern "C" int ipdm_subsample2_f32(const float* x, float* out, int planes, int H, int W, void* stream) {
-  IPDM_REQUIRE(planes >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0);
+extern "C" int ipdm_subsample2_f32(const float* x, float* out, int planes, int H, int W, int oy, int ox, int Ho, int Wo,
+                                   void* stream) {
+  IPDM_REQUIRE(planes >= 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && oy >= 0 && ox >= 0);
+  IPDM_REQUIRE(2 * (Ho - 1) + oy < H && 2 * (Wo - 1) + ox < W);
   if (planes == 0) return IPDM_OK;
   IPDM_REQUIRE(x && out);
-  const int64_t n = (int64_t)planes * (H / 2) * (W / 2);
+  const int64_t n = (int64_t)planes * Ho * Wo;
   hipLaunchKernelGGL(subsample2_kernel, dim3(ipdm_ew_grid(n, 256)), dim3(256), 0, ipdm_stream(stream), x, out, (long long)n,
-                     H / 2, W / 2);
+                     H, W, Ho, Wo, oy, ox);
   return ipdm_launch_status();
 }
 

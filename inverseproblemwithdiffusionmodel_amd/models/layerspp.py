@@ -98,7 +98,7 @@ class Downsample(nn.Module):
         super().__init__()
         out_ch = out_ch if out_ch else in_ch
         if not fir and with_conv:
-            raise NotImplementedError("strided 3x3 Downsample (fir=False, with_conv=True) needs a stride-2 convolution")
+            self.Conv_0 = conv3x3(in_ch, out_ch)                 # applied with stride 2, padding 0 (see forward)
         if fir and with_conv:
             self.Conv2d_0 = up_or_down_sampling.Conv2d(in_ch, out_ch, kernel=3, down=True, resample_kernel=fir_kernel,
                                                        use_bias=True, kernel_init=default_init())
@@ -106,6 +106,11 @@ class Downsample(nn.Module):
 
     def forward(self, x):
         if not self.fir:
+            if self.with_conv:
+                # F.pad(x, (0, 1, 0, 1)) then conv3x3(stride 2, padding 0): the stride-1 kernel sampled at the odd positions
+                x = torch.nn.functional.pad(x, (0, 1, 0, 1))
+                c = self.Conv_0
+                return ops.conv2d_stride2_valid(x.contiguous(), c.packed(), None if c.bias is None else c.bias.data, 3)
             return up_or_down_sampling.naive_downsample_2d(x, 2)          # F.avg_pool2d(x, 2, 2)
         if not self.with_conv:
             return up_or_down_sampling.downsample_2d(x, self.fir_kernel, factor=2)

@@ -45,9 +45,11 @@ class NCSNpp(nn.Module):
         assert progressive in ['none', 'output_skip', 'residual']
         assert progressive_input in ['none', 'input_skip', 'residual']
         assert embedding_type in ['fourier', 'positional']
-        if resblock_type != 'biggan' or progressive == 'residual' or progressive_input == 'residual':
-            raise NotImplementedError("only the BigGAN / output_skip / input_skip variant (every shipped VE NCSN++ "
-                                      "config) is built; 'ddpm' and 'residual' need strided / transposed convolutions")
+        if resblock_type != 'biggan' or progressive == 'residual':
+            raise NotImplementedError("built: BigGAN blocks with progressive in {none, output_skip} and progressive_input in "
+                                      "{none, input_skip, residual} (every shipped configs/ve NCSN++ config); the 'ddpm' "
+                                      "block type and the 'residual' output pyramid (whose fir up-sampling convolution raises "
+                                      "in the reference itself, up_or_down_sampling.py:126) are not")
         combiner = functools.partial(Combine, method=config.model.progressive_combine.lower())
 
         modules = []
@@ -66,6 +68,8 @@ class NCSNpp(nn.Module):
             self.pyramid_upsample = layerspp.Upsample(fir=fir, fir_kernel=fir_kernel, with_conv=False)
         if progressive_input == 'input_skip':
             self.pyramid_downsample = layerspp.Downsample(fir=fir, fir_kernel=fir_kernel, with_conv=False)
+        elif progressive_input == 'residual':
+            pyramid_downsample = functools.partial(layerspp.Downsample, fir=fir, fir_kernel=fir_kernel, with_conv=True)
         ResnetBlock = functools.partial(ResnetBlockBigGAN, act=act, dropout=dropout, fir=fir, fir_kernel=fir_kernel,
                                         init_scale=init_scale, skip_rescale=skip_rescale, temb_dim=nf * 4)
 
@@ -88,6 +92,9 @@ class NCSNpp(nn.Module):
                     modules.append(combiner(dim1=input_pyramid_ch, dim2=in_ch))
                     if config.model.progressive_combine.lower() == 'cat':
                         in_ch *= 2
+                elif progressive_input == 'residual':
+                    modules.append(pyramid_downsample(in_ch=input_pyramid_ch, out_ch=in_ch))
+                    input_pyramid_ch = in_ch
                 hs_c.append(in_ch)
 
         in_ch = hs_c[-1]
@@ -156,6 +163,12 @@ class NCSNpp(nn.Module):
                     input_pyramid = self.pyramid_downsample(input_pyramid)
                     h = modules[m_idx](input_pyramid, h)
                     m_idx += 1
+                elif self.progressive_input == 'residual':
+                    input_pyramid = modules[m_idx](input_pyramid)        # FIR + stride-2 convolution of the pyramid
+                    m_idx += 1
+                    s_ = float(1.0 / np.sqrt(2.0)) if self.skip_rescale else 1.0
+                    input_pyramid = ops.axpby(input_pyramid, h, s_, s_)  # (input_pyramid + h) / sqrt(2)
+                    h = input_pyramid
                 hs.append(h)
 
         h = hs[-1]

@@ -63,9 +63,18 @@ def upsample_conv_2d(x, w, k=None, factor=2, gain=1):
                               "models/up_or_down_sampling.py:126); no shipped config reaches it")
 
 
-def conv_downsample_2d(x, w, k=None, factor=2, gain=1):
-    raise NotImplementedError("conv_downsample_2d needs a stride-2 convolution; only reached with resblock_type='ddpm' "
-                              "or progressive*='residual', which no shipped VE config uses")
+def conv_downsample_2d(x, w, k=None, factor=2, gain=1, packed=None, bias=None):
+    """FIR low-pass (padding once, before both operations) followed by a stride-`factor` VALID convolution with `w`
+    [Cout, Cin, k, k] (models/up_or_down_sampling.py:144-178).  The strided convolution runs as the stride-1 MFMA
+    convolution sampled at the odd positions; `packed`: the pre-packed weight (ops.conv_weight(w))."""
+    assert isinstance(factor, int) and factor == 2, "only the factor-2 form any model uses is built"
+    _outC, _inC, convH, convW = w.shape
+    assert convW == convH and convW % 2 == 1
+    k = [1] * factor if k is None else k
+    fir = _fir(k, gain, x.device)
+    p = (fir.shape[0] - factor) + (convW - 1)
+    x = upfirdn2d(x, fir, pad=((p + 1) // 2, p // 2))
+    return ops.conv2d_stride2_valid(x, ops.conv_weight(w) if packed is None else packed, bias, convW)
 
 
 class Conv2d(ops.PackedWeightMixin, nn.Module):
@@ -87,7 +96,8 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
     def forward(self, x):
         if self.up:
             return upsample_conv_2d(x, self.weight, k=self.resample_kernel)
-        if self.down:
-            return conv_downsample_2d(x, self.weight, k=self.resample_kernel)
         packed = self._cache.get(self.weight, "direct_" + ops.CONV_IMPL, ops.conv_weight)
+        if self.down:                   # the bias rides in the convolution epilogue (= x + bias.reshape(1, -1, 1, 1) afterwards)
+            return conv_downsample_2d(x, self.weight, k=self.resample_kernel, packed=packed,
+                                      bias=self.bias.data if self.use_bias else None)
         return ops.conv2d(x, packed, self.bias.data if self.use_bias else None)

@@ -248,13 +248,24 @@ def zero_insert2(x):
     return out
 
 
-def subsample2(x):
-    """(..., H, W) -> (..., H/2, W/2): the even positions"""
+def subsample2(x, offset=(0, 0), size=None):
+    """(..., H, W) -> (..., Ho, Wo): x[..., 2i + oy, 2j + ox]; default: the even positions, (H/2, W/2)"""
     x = _gpu(x, torch.float32, "x")
     H, W = x.shape[-2:]
-    out = torch.empty(tuple(x.shape[:-2]) + (H // 2, W // 2), dtype=torch.float32, device=x.device)
-    call("ipdm_subsample2_f32", _ptr(x), _ptr(out), x.numel() // (H * W), H, W, _stream())
+    oy, ox = offset
+    Ho, Wo = ((H - oy + 1) // 2, (W - ox + 1) // 2) if size is None else size
+    out = torch.empty(tuple(x.shape[:-2]) + (Ho, Wo), dtype=torch.float32, device=x.device)
+    call("ipdm_subsample2_f32", _ptr(x), _ptr(out), x.numel() // (H * W), H, W, oy, ox, Ho, Wo, _stream())
     return out
+
+
+def conv2d_stride2_valid(x, wt, bias=None, ksize=3):
+    """F.conv2d(x, w, stride=2, padding=0) for an odd kernel on the stride-1 MFMA kernel: the 'same' convolution sampled at
+    (k//2, k//2) + 2(i, j).  wt: the packed weight of the same layer (conv_weight)."""
+    H, W = x.shape[-2:]
+    full = conv2d(x, wt, bias)
+    o = ksize // 2
+    return subsample2(full, (o, o), ((H - ksize) // 2 + 1, (W - ksize) // 2 + 1))
 
 
 def in_prelu_fwd(x, slope, eps=1e-5):

@@ -195,3 +195,48 @@ def test_ode_sampler_golden(net, golden, tag, kw):
     assert abs(int(nfe) - int(g[f"{tag}_nfe"])) <= 12
     tol = 2 * (kw["rtol"] * np.abs(ref).max() + kw["atol"])           # the solver's own accuracy target bounds the comparison
     assert np.abs(x.cpu().numpy() - ref).max() <= tol
+
+
+def test_strided_conv_variants_golden(golden):
+    """conv_downsample_2d (FIR + stride-2 VALID convolution), Downsample(fir=False, with_conv=True) (pad + stride-2 conv) and
+    Downsample(fir=True, with_conv=True) (up_or_down_sampling.Conv2d(down=True) + bias) vs the reference's outputs (g27):
+    the strided convolution runs as the stride-1 MFMA kernel sampled at the odd positions"""
+    from inverseproblemwithdiffusionmodel_amd.models import up_or_down_sampling as uds, layerspp
+    g = golden("g27_pp_variants")
+    x = torch.from_numpy(g["cd_x"]).cuda()
+    y = uds.conv_downsample_2d(x, torch.from_numpy(g["cd_w"]).cuda(), k=(1, 3, 3, 1)).cpu().numpy()
+    assert y.shape == g["cd_y"].shape
+    np.testing.assert_allclose(y, g["cd_y"], atol=1e-5)
+    y1 = uds.conv_downsample_2d(x, torch.from_numpy(g["cd_w1"]).cuda(), k=(1, 3, 3, 1)).cpu().numpy()
+    np.testing.assert_allclose(y1, g["cd_y1"], atol=1e-5)
+    ds = layerspp.Downsample(in_ch=5, out_ch=6, with_conv=True, fir=False)
+    ds.load_state_dict(state_dict_from_golden(g, "ds"), strict=True)
+    np.testing.assert_allclose(ds.cuda()(x).cpu().numpy(), g["ds_y"], atol=1e-5)
+    df = layerspp.Downsample(in_ch=5, out_ch=6, with_conv=True, fir=True)
+    df.load_state_dict(state_dict_from_golden(g, "df"), strict=True)
+    np.testing.assert_allclose(df.cuda()(x).cpu().numpy(), g["df_y"], atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,emb", [("res_fourier", "fourier"), ("res_positional", "positional")])
+def test_ncsnpp_cifar_layout_golden(golden, tag, emb):
+    """NCSN++ as configs/ve/cifar10_ncsnpp*.py lay it out: no output pyramid (final GroupNorm + conv), input pyramid
+    'residual' (FIR + stride-2 convolution, combined with (a + b)/sqrt 2), Fourier or positional embedding"""
+    from inverseproblemwithdiffusionmodel_amd.models import ncsnpp
+    from inverseproblemwithdiffusionmodel_amd.synthetic import synth_state_dict
+    g = golden("g27_pp_variants")
+    cfg = tiny_cfg()
+    cfg.model.progressive, cfg.model.progressive_input, cfg.model.embedding_type = "none", "residual", emb
+    cfg.training.continuous = emb == "fourier"
+    m = ncsnpp.NCSNpp(cfg)
+    keys = [f"{k}:{','.join(map(str, v.shape))}" for k, v in m.state_dict().items()]
+    assert keys == list(g[f"{tag}_keys"])                                      # the reference's all_modules.N.* layout
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=273)
+    for k, v in m.state_dict().items():
+        if k.endswith(".W"):
+            sd[k] = torch.randn(v.shape, generator=torch.Generator().manual_seed(274)) * 16.0
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        y = m(torch.from_numpy(g[f"{tag}_x"]).cuda(), torch.from_numpy(g[f"{tag}_cond"]).cuda()).cpu().numpy()
+    ref = g[f"{tag}_y"]
+    assert np.abs(y - ref).max() <= 2e-4 * np.abs(ref).max()
