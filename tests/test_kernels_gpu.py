@@ -500,7 +500,8 @@ def test_meanpool2(ops):
 
 
 @pytest.mark.parametrize("ish,osh", [((6, 5), (12, 10)), ((16, 16), (32, 32)), ((64, 64), (128, 128)),
-                                     ((16, 16), (16, 16)), ((5, 7), (11, 9)), ((1, 1), (4, 4))])
+                                     ((16, 16), (16, 16)), ((5, 7), (11, 9)), ((1, 1), (4, 4)),
+                                     ((32, 32), (64, 64)), ((20, 24), (52, 60)), ((8, 128), (24, 256)), ((12, 16), (12, 32))])
 def test_bilinear(ops, ish, osh):
     gen = torch.Generator().manual_seed(12)
     x = torch.randn(2, 3, *ish, generator=gen)
