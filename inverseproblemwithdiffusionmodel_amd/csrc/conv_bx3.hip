@@ -308,37 +308,87 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
   }
 
   if (a.dbg) t2 = __builtin_amdgcn_s_memtime();
-  // ---- epilogue: bias, residual, coalesced stores (lane <-> pixel) ----
+  // ---- epilogue: bias, residual, coalesced stores (lane <-> pixel).  Loads are issued in batches ahead of their use:
+  //      the bias of all of this thread's channels first, then the 16 residual values of a (pixel tile, channel tile)
+  //      pair together, one pair ahead of the pair being stored.  (One element at a time -- load, wait, add, store --
+  //      exposed every load's full latency, and behind run-time branches hipcc cannot count the stores in flight, so it
+  //      also waited for the previous element's stores.)  The loads are unconditional (addresses clamped into the tensor,
+  //      an absent bias / residual reads the weight blob instead) and each batch passes through an empty asm that
+  //      "redefines" it, so the one counted wait sits there and no use further down waits again. ----
   const int co0 = co_tile * C::CO_T;
+  const bool finish = a.ksplit <= 1;             // else: raw partial sum; bias / residual / activation in the reduce pass
+  const bool has_res = finish && a.residual != nullptr, has_bias = finish && a.bias != nullptr;
+  const float* const res_p = has_res ? a.residual : a.wt;
+  const float* const bias_p = has_bias ? a.bias : a.wt;
+  const size_t co_stride = has_res ? (size_t)a.D * HW : 0;
+  float bv[NCT][16];
 #pragma unroll
-  for (int n = 0; n < NPT; ++n) {
+  for (int m = 0; m < NCT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + (wco * NCT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      bv[m][r] = bias_p[has_bias ? (co < a.Cout ? co : a.Cout - 1) : 0];
+    }
+  constexpr int NBATCH = NPT * NCT;
+  float rv[2][16];
+  auto pixel_of = [&](int n, int& gy, int& gx) {
     const int tile = wpx * NPT + n;
-    const int prow = PW == 32 ? tile : tile * 2 + (j >> 4);
-    const int pcol = PW == 32 ? j : (j & 15);
-    const int gy = y0 + prow, gx = x0 + pcol;
-    if (gy >= a.H || gx >= a.W) continue;
+    gy = y0 + (PW == 32 ? tile : tile * 2 + (j >> 4));
+    gx = x0 + (PW == 32 ? j : (j & 15));
+  };
+  auto load_res = [&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int n = q / NCT, m = q % NCT;
+    int gy, gx;
+    pixel_of(n, gy, gx);
+    gy = gy < a.H ? gy : a.H - 1;
+    gx = gx < a.W ? gx : a.W - 1;
+    const int cob = co0 + (wco * NCT + m) * 32 + 4 * h;
+    const size_t pb = has_res ? ((size_t)b * a.Cout * a.D + z) * HW + (size_t)gy * a.W + gx : 0;
 #pragma unroll
-    for (int m = 0; m < NCT; ++m) {
+    for (int r = 0; r < 16; ++r) {
+      int co = cob + (r & 3) + 8 * (r >> 2);
+      co = co < a.Cout ? co : a.Cout - 1;
+      rv[q & 1][r] = res_p[pb + co * co_stride];
+    }
+  };
+#pragma unroll
+  for (int m = 0; m < NCT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bv[m][r]));
+  load_res(std::integral_constant<int, 0>{});
+  static_for<NBATCH>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int n = q / NCT, m = q % NCT;
+    if constexpr (q + 1 < NBATCH) load_res(std::integral_constant<int, q + 1>{});
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(rv[q & 1][r]));
+    int gy, gx;
+    pixel_of(n, gy, gx);
+    if (gy < a.H && gx < a.W) {
+      const int cob = co0 + (wco * NCT + m) * 32 + 4 * h;      // channel of r = 0; r adds (r & 3) + 8 * (r >> 2)
+      const size_t ob = (((size_t)b * a.Cout + cob) * a.D + z) * HW + (size_t)gy * a.W + gx;
+      const size_t os = (size_t)a.D * HW;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co0 + (wco * NCT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (co < a.Cout) {
-          const size_t o = (((size_t)b * a.Cout + co) * a.D + z) * HW + (size_t)gy * a.W + gx;
+        const int dco = (r & 3) + 8 * (r >> 2);
+        if (cob + dco < a.Cout) {
+          const size_t o = ob + dco * os;
           float v;
           if constexpr (PW == 16) v = tot[m][n][r];
           else v = acc[m][n][r];
-          if (a.ksplit > 1) {                    // raw partial sum; bias / residual / activation in the reduce pass
+          if (!finish) {
             a.partial[(size_t)ks * a.B * a.Cout * cs + o] = v;
             continue;
           }
-          if (a.bias) v += a.bias[co];
-          if (a.residual) v += a.residual[o];
+          if (has_bias) v += bv[m][r];
+          if (has_res) v += rv[q & 1][r];
           if (a.out) a.out[o] = v;
           if (a.out_act) a.out_act[o] = a.act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, a.act_out);
         }
       }
     }
-  }
+  });
   if (a.dbg) {                                   // tuning aid (ipdm_debug_set_stamp_buffer); NULL in production
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long t3 = __builtin_amdgcn_s_memtime();

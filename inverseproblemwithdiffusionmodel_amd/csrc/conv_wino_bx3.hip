@@ -341,6 +341,29 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
     out_ok = tile0 + tile < THS * TWS * d * d;
     tile_origin(out_ok ? tile0 + tile : 0, oy, ox);
   }
+  // bias and residual of BOTH rounds are fetched here, before the exchange (unconditional loads: an absent operand or an
+  // out-of-range tile reads the weight blob instead, so hipcc can count them); next to their use every one of them
+  // exposed its full latency, with nothing else resident on the CU to cover it
+  const bool has_res = a.residual != nullptr, has_bias = a.bias != nullptr;
+  const float* const res_p = has_res ? a.residual : a.wt;
+  const float* const bias_p = has_bias ? a.bias : a.wt;
+  const bool res_ok = has_res && out_ok;
+  const int rd = res_ok ? d : 0;
+  float bv[2][4];
+  float2 rv[2][4][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = co0 + c * 32 + cg * 4 + i;
+      bv[c][i] = bias_p[has_bias ? co : 0];
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const size_t o = res_ok ? ((size_t)b * a.Cout + co) * HW + (size_t)(oy + (SMALL ? d * ii : ii)) * a.W + ox : 0;
+        if constexpr (SMALL) rv[c][i][ii] = make_float2(res_p[o], res_p[o + rd]);
+        else rv[c][i][ii] = *reinterpret_cast<const float2*>(res_p + o);
+      }
+    }
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     if (c > 0) __syncthreads();                              // the previous round's reads are done
@@ -354,6 +377,12 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
           lds[((p0 + pi) * 32 + col) * X_TILES + tg * 32 + j] = acc[pi][c][tg][r];
         }
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                            // the one counted wait for this round's loads sits here
+      asm volatile("" : "+v"(bv[c][i]));
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) asm volatile("" : "+v"(rv[c][i][ii].x), "+v"(rv[c][i][ii].y));
+    }
     if (out_ok) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -368,17 +397,17 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
           tt[0][q] = m[0 * 4 + q] + m[1 * 4 + q] + m[2 * 4 + q];
           tt[1][q] = m[1 * 4 + q] - m[2 * 4 + q] - m[3 * 4 + q];
         }
-        const float bias = a.bias ? a.bias[co] : 0.f;
+        const float bias = has_bias ? bv[c][i] : 0.f;
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
           float y0v = tt[ii][0] + tt[ii][1] + tt[ii][2] + bias;
           float y1v = tt[ii][1] - tt[ii][2] - tt[ii][3] + bias;
           const size_t o = ((size_t)b * a.Cout + co) * HW + (size_t)(oy + (SMALL ? d * ii : ii)) * a.W + ox;
+          if (has_res) {
+            y0v += rv[c][i][ii].x;
+            y1v += rv[c][i][ii].y;
+          }
           if constexpr (SMALL) {
-            if (a.residual) {
-              y0v += a.residual[o];
-              y1v += a.residual[o + d];
-            }
             if (a.out) {
               a.out[o] = y0v;
               a.out[o + d] = y1v;
@@ -388,11 +417,6 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
               a.out_act[o + d] = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
             }
           } else {
-            if (a.residual) {
-              const float2 rr2 = *reinterpret_cast<const float2*>(a.residual + o);
-              y0v += rr2.x;
-              y1v += rr2.y;
-            }
             if (a.out) *reinterpret_cast<float2*>(a.out + o) = make_float2(y0v, y1v);
             if (a.out_act) {
               const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
@@ -436,7 +460,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   constexpr int QC = TX / 2 + 2, RC4 = 4 * QC;               // quads / floats per raw row (x0-4 .. x0+2TX+3)
   constexpr int QN = (2 * TY + 2) * QC;                       // quads per channel
   constexpr int NI = (X_KC * QN + 63) / 64;                   // wave-instructions per chunk
-  static_assert(NI <= 32 && NI * 256 <= X_R_ELEMS, "quad image fits the raw stage");
+  static_assert(NI >= 24 && NI <= 32 && NI * 256 <= X_R_ELEMS, "quad image fits the raw stage; pieces 0..23 exist");
   static_assert(TX * TY == X_TILES, "64 tiles per workgroup");
   constexpr int RC = 2 * TX + 2, RR = 2 * TY + 2;            // raw region: 34 x 10 or 18 x 18 pixels (<= X_RCH)
   static_assert(RC * RR <= X_RCH, "raw region fits its LDS slot");
@@ -484,12 +508,16 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   // chunk's 16 channels are one packed image of NI x 64 quads, wave w issues pieces w, w+8, w+16, w+24
   int dma_off[DMA4 ? 4 : 6];
   int dma_b = 0;                                              // image index the offsets belong to
+  // every wave issues exactly four pieces per chunk (a wave without a k-th piece repeats its previous one: same bytes to
+  // the same place), so that the number of DMA instructions in flight is a compile-time constant: with a wave-uniform
+  // branch around them hipcc cannot count, and waits for vmcnt(0) -- i.e. for the DMA -- at the next fragment use
+  auto dma_piece = [&](int k) { return wave + 8 * k < NI ? wave + 8 * k : wave + 8 * (k - 1); };
   auto set_dma_geo = [&](const Geo& g) {
     dma_b = g.b;
     if constexpr (DMA4) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int e = (wave + 8 * k) * 64 + lane;
+        const int e = dma_piece(k) * 64 + lane;
         const int cin = e / QN, qq = e - cin * QN;
         const int rr = qq / QC, qc = qq - rr * QC;
         const int gy = g.y0 - 1 + rr, gx0 = g.x0 - 4 + 4 * qc;
@@ -511,13 +539,12 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     if constexpr (DMA4) {
       const int soff = (int)(((size_t)dma_b * a.Cin + chunk * X_KC) * HW * 4);
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (wave + 8 * k < NI) {                              // wave-uniform
+      for (int k = 0; k < 4; ++k) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the 16-byte form only exists for gfx950: keep it out of the host pass
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(rs + (wave + 8 * k) * 256),
-                                                   16, dma_off[k], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(rs + dma_piece(k) * 256),
+                                                 16, dma_off[k], soff, 0, 0);
 #endif
-        }
+      }
     } else {
 #pragma unroll
       for (int cl = 0; cl < 2; ++cl) {
@@ -695,9 +722,49 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     float* ms = lds + ((g - 1) & 1) * X_V_ELEMS;              // M[pos 16][co 32][tile 32]
     const int etile = tid & 31, ecg = tid >> 5;               // this thread: tile, channels 2*ecg, 2*ecg+1 of the 32
     const int co0 = cur_g.co_tile * X_CO;
+    // bias and residual of a round are fetched ONE ROUND AHEAD (round 0: before the first exchange): issued next to their
+    // use, each of the four residual loads of a round exposed a full HBM latency to all eight waves at once
+    // (8x8 tile blocks: same round, before the exchange -- one buffer; the second costs that instantiation nine spills)
+    constexpr int NR = POOL ? 1 : 2;
+    constexpr bool AHEAD = TX == 16;
+    float2 resv[AHEAD ? 2 : 1][2][NR];
+    float biasv[AHEAD ? 2 : 1][2];
+    auto out_index = [&](int c, int tg, int i, int ii) -> size_t {
+      const int T = tg * 32 + etile;
+      const int oy = cur_g.y0 + 2 * (T / TX), ox = cur_g.x0 + 2 * (T % TX);
+      const int co = co0 + c * 32 + ecg * 2 + i;
+      if constexpr (POOL) return (((size_t)cur_g.b * a.Cout + co) * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1);
+      return ((size_t)cur_g.b * a.Cout + co) * HW + (size_t)(oy + ii) * a.W + ox;
+    };
+    auto in_range = [&](int tg) {
+      const int T = tg * 32 + etile;
+      return cur_g.y0 + 2 * (T / TX) < a.H && cur_g.x0 + 2 * (T % TX) < a.W;
+    };
+    // (unconditional loads -- an absent operand or an out-of-range tile reads the weight blob -- so that hipcc can count
+    // what is in flight: behind a branch it waits for vmcnt(0), i.e. also for the batch just issued)
+    const bool has_res = a.residual != nullptr, has_bias = a.bias != nullptr;
+    const float* const res_p = has_res ? a.residual : a.wt;
+    const float* const bias_p = has_bias ? a.bias : a.wt;
+    auto prefetch = [&](auto rc) {
+      constexpr int rnd = decltype(rc)::value;
+      constexpr int c = rnd >> 1, tg = rnd & 1, bf = AHEAD ? rnd & 1 : 0;
+      const bool res_ok = has_res && in_range(tg);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        biasv[bf][i] = bias_p[has_bias ? co0 + c * 32 + ecg * 2 + i : 0];
+#pragma unroll
+        for (int ii = 0; ii < NR; ++ii) {
+          const size_t o = res_ok ? out_index(c, tg, i, ii) : 0;
+          if constexpr (POOL) resv[bf][i][ii] = make_float2(res_p[o], 0.f);
+          else resv[bf][i][ii] = *reinterpret_cast<const float2*>(res_p + o);
+        }
+      }
+    };
+    if constexpr (AHEAD) prefetch(std::integral_constant<int, 0>{});
     static_for<4>([&](auto rc) {
       constexpr int rnd = decltype(rc)::value;
-      constexpr int c = rnd >> 1, tg = rnd & 1;
+      constexpr int c = rnd >> 1, tg = rnd & 1, bf = AHEAD ? rnd & 1 : 0;
+      if constexpr (!AHEAD) prefetch(rc);
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi)
 #pragma unroll
@@ -706,13 +773,11 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
           ms[((p0 + pi) * 32 + col) * 32 + j] = acc[pi][c][tg][rr];
         }
       __syncthreads();
-      const int T = tg * 32 + etile;
-      const int oy = cur_g.y0 + 2 * (T / TX), ox = cur_g.x0 + 2 * (T % TX);
-      if (oy < a.H && ox < a.W) {
+      if constexpr (AHEAD && rnd < 3) prefetch(std::integral_constant<int, rnd + 1>{});
+      if (in_range(tg)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int cl = ecg * 2 + i;
-          const int co = co0 + c * 32 + cl;
           float m[16];
 #pragma unroll
           for (int p = 0; p < 16; ++p) m[p] = ms[(p * 32 + cl) * 32 + etile];
@@ -722,15 +787,15 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
             tt[0][qq] = m[0 * 4 + qq] + m[1 * 4 + qq] + m[2 * 4 + qq];
             tt[1][qq] = m[1 * 4 + qq] - m[2 * 4 + qq] - m[3 * 4 + qq];
           }
-          const float bias = a.bias ? a.bias[co] : 0.f;
+          const float bias = has_bias ? biasv[bf][i] : 0.f;
           if constexpr (POOL) {
             // ConvMeanPool: (y[::2,::2] + y[1::2,::2] + y[::2,1::2] + y[1::2,1::2]) / 4 in the reference's order; the
             // output tile IS the 2x2 pooling window, so the full-resolution result is never written
             const float y00 = tt[0][0] + tt[0][1] + tt[0][2] + bias, y01 = tt[0][1] - tt[0][2] - tt[0][3] + bias;
             const float y10 = tt[1][0] + tt[1][1] + tt[1][2] + bias, y11 = tt[1][1] - tt[1][2] - tt[1][3] + bias;
             float v = (((y00 + y10) + y01) + y11) * 0.25f;
-            const size_t o = (((size_t)cur_g.b * a.Cout + co) * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1);
-            if (a.residual) v += a.residual[o];
+            const size_t o = out_index(c, tg, i, 0);
+            if (has_res) v += resv[bf][i][0].x;
             if (a.out) a.out[o] = v;
             if (a.out_act) a.out_act[o] = a.act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, a.act_out);
           } else {
@@ -738,11 +803,10 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
           for (int ii = 0; ii < 2; ++ii) {
             float y0v = tt[ii][0] + tt[ii][1] + tt[ii][2] + bias;
             float y1v = tt[ii][1] - tt[ii][2] - tt[ii][3] + bias;
-            const size_t o = ((size_t)cur_g.b * a.Cout + co) * HW + (size_t)(oy + ii) * a.W + ox;
-            if (a.residual) {
-              const float2 rr2 = *reinterpret_cast<const float2*>(a.residual + o);
-              y0v += rr2.x;
-              y1v += rr2.y;
+            const size_t o = out_index(c, tg, i, ii);
+            if (has_res) {
+              y0v += resv[bf][i][ii].x;
+              y1v += resv[bf][i][ii].y;
             }
             if (a.out) *reinterpret_cast<float2*>(a.out + o) = make_float2(y0v, y1v);
             if (a.out_act) {
