@@ -654,11 +654,21 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   if (a.dbg) t1 = __builtin_amdgcn_s_memtime();
 
   int g = 0;                                                  // chunks done so far: stage parity
+#ifdef IPDM_WBX3_TRACE
+  unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // step timeline of chunk 2 of the second tile (diagnostic build)
+#define IPDM_TR(k) if (a.dbg && trace_now) tr[k] = __builtin_amdgcn_s_memtime()
+#else
+#define IPDM_TR(k)
+#endif
   while (true) {
     const int next_tile = tile + S;
     const bool has_next = next_tile < x_end;
     const Geo next_g = geo_of(has_next ? next_tile : tile);
     for (int ch = 0; ch < n_chunks; ++ch, ++g) {
+#ifdef IPDM_WBX3_TRACE
+      const bool trace_now = g == n_chunks + 2;
+#endif
+      IPDM_TR(0);
       const float* cur = lds + (g & 1) * X_V_ELEMS;
       float* nxt = lds + ((g + 1) & 1) * X_V_ELEMS;
       // the chunk two ahead in the stream (DMA target) and the one after this (A fragments of position p0)
@@ -701,19 +711,26 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
         }
         if constexpr (st < 3) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
         constexpr bool XFORM = st == 0;
-        if constexpr (XFORM) __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+        constexpr int XRD = 16, XVALU = 12, XST = 3, MIDSTEP = 0;   // patch reads, VALU per MFMA, patch stores; barrier after step 0
+        if constexpr (XFORM) __builtin_amdgcn_sched_group_barrier(0x100, XRD, 0);
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x006, XFORM ? 12 : 5, 0);
-          if constexpr (XFORM) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, XFORM ? XVALU : 5, 0);
+          if constexpr (XFORM) __builtin_amdgcn_sched_group_barrier(0x200, XST, 0);
           if constexpr (st < 3) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (st == 0) __syncthreads();               // everyone has read the raw stage
+        IPDM_TR(1 + st);
+        if constexpr (st == MIDSTEP) {
+          __syncthreads();                                    // everyone has read the raw stage
+          IPDM_TR(5);
+        }
       });
       __builtin_amdgcn_s_waitcnt(0);                          // the DMA has landed
+      IPDM_TR(6);
       __syncthreads();
+      IPDM_TR(7);
     }
     if (a.dbg) t2 = __builtin_amdgcn_s_memtime();
 
@@ -832,8 +849,16 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       unsigned long long* d4 = a.dbg + (size_t)blockIdx.x * 4;
       d4[0] = t0; d4[1] = t1; d4[2] = t2; d4[3] = t3;
     }
+#ifdef IPDM_WBX3_TRACE
+    if (lane == 0) {
+      unsigned long long* d8 = a.dbg + (size_t)gridDim.x * 4 + ((size_t)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d8[k] = tr[k];
+    }
+#endif
   }
 }
+#undef IPDM_TR
 
 
 // ---- 128 output channels x 32 tiles per workgroup (Cout % 128 == 0) -------------------------------------------------

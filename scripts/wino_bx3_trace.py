@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""step-level timeline of one chunk of the split-bf16 Winograd kernel (needs a build with -DIPDM_WBX3_TRACE)"""
+"""step-level timeline of one chunk (chunk 2 of a workgroup's second tile) of the persistent split-bf16 Winograd kernel;
+needs a diagnostic build: scripts/build_variant.sh trace conv_wino_bx3.hip -DIPDM_WBX3_TRACE, run with IPDM_LIB=_variants/libipdm_trace.so"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from inverseproblemwithdiffusionmodel_amd import ops, _lib
 B, ci, co, hw = 28, 128, 128, 128
 x = torch.randn(B, ci, hw, hw, device="cuda"); w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
 U = ops.conv_wino_bx3_weight(w)
-nblk = B * (hw // 8) * (hw // 32) * (co // 64)
+nblk = 256                                       # persistent kernel: one workgroup per CU
 buf = torch.zeros(nblk * 4 + nblk * 64, dtype=torch.int64, device="cuda")
 for _ in range(3): ops.conv2d_wino_bx3(x, U)
 torch.cuda.synchronize()
@@ -23,3 +24,8 @@ print("median cycles per segment, per wave (rows = wave 0..7):")
 print("   " + "  ".join(f"{n:>14s}" for n in ["st0(+B0 split)", "mid barrier", "step1 (dma)", "step2", "step3", "dma wait", "end barrier"]))
 for wv in range(8):
     print(f"w{wv} " + "  ".join(f"{med[wv, i]:14.0f}" for i in range(7)), f"  total {med[wv].sum():.0f}")
+for blk in (0, 100):
+    base = t[blk, :, 0].min()
+    print(f"workgroup {blk}: stamps relative to the first wave's chunk start (start, st0, mid-barrier, st1, st2, st3, dma, end-barrier)")
+    for wv in range(8):
+        print(f"w{wv} " + " ".join(f"{t[blk, wv, k] - base:7.0f}" for k in seq))
