@@ -196,6 +196,10 @@ int ipdm_meanpool2_f32(const float* x, float* y, int planes, int H, int W, void*
 /* bilinear resize, align_corners=True: out = act(resize(x) [+ out]); accumulate != 0 adds the previous out */
 int ipdm_bilinear_f32(const float* x, float* out, int planes, int in_h, int in_w, int out_h, int out_w,
                       int accumulate, int act /* applied to the value written */, void* stream);
+/* trilinear resize, align_corners=True, of [planes][D][H][W] volumes (the 3-D MSF block's F.interpolate,
+ * ncsn/models/layers3d.py:185,214); same accumulate / act convention */
+int ipdm_trilinear_f32(const float* x, float* out, int planes, int in_d, int in_h, int in_w, int out_d, int out_h,
+                       int out_w, int accumulate, int act, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * NCSN++ / predictor-corrector extras (reference: torch.nn.GroupNorm(eps 1e-6) in models/layerspp.py:66,219

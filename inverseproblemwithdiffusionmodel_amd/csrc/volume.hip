@@ -73,6 +73,33 @@ __global__ __launch_bounds__(256) void temporal_taps_kernel(const float* __restr
   }
 }
 
+// trilinear resize, align_corners=True (F.interpolate(mode='trilinear') of the 3-D MSF block, layers3d.py:185,214): one
+// output element per thread, the eight taps combined in ATen's order (width, then height, then depth)
+__global__ __launch_bounds__(256) void trilinear_kernel(const float* __restrict__ x, float* out, long long total, int id,
+                                                        int ih, int iw, int od, int oh, int ow, float sd, float sh, float sw,
+                                                        int accumulate, int act) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ox = (int)(i % ow);
+    long long t = i / ow;
+    const int oy = (int)(t % oh);
+    t /= oh;
+    const int oz = (int)(t % od);
+    const long long plane = t / od;
+    const float fz = sd * oz, fy = sh * oy, fx = sw * ox;
+    const int z0 = (int)fz, y0 = (int)fy, x0 = (int)fx;
+    const int zp = z0 < id - 1 ? 1 : 0, yp = y0 < ih - 1 ? 1 : 0, xp = x0 < iw - 1 ? 1 : 0;
+    const float lz1 = fz - z0, lz0 = 1.f - lz1, ly1 = fy - y0, ly0 = 1.f - ly1, lx1 = fx - x0, lx0 = 1.f - lx1;
+    const float* p00 = x + ((plane * id + z0) * ih + y0) * (long long)iw + x0;
+    const float* p01 = p00 + (long long)yp * iw;
+    const float* p10 = p00 + (long long)zp * ih * iw;
+    const float* p11 = p10 + (long long)yp * iw;
+    float v = lz0 * (ly0 * (lx0 * p00[0] + lx1 * p00[xp]) + ly1 * (lx0 * p01[0] + lx1 * p01[xp])) +
+              lz1 * (ly0 * (lx0 * p10[0] + lx1 * p10[xp]) + ly1 * (lx0 * p11[0] + lx1 * p11[xp]));
+    if (accumulate) v += out[i];
+    out[i] = ipdm_act(v, act);
+  }
+}
+
 }  // namespace
 
 extern "C" int ipdm_maxpool3d5_f32(const float* x, float* y, int planes, int D, int H, int W, void* stream) {
@@ -93,5 +120,19 @@ extern "C" int ipdm_temporal_taps_f32(const float* x, float* out, int planes, in
   const int64_t total = (int64_t)planes * 4 * S * T_out;
   hipLaunchKernelGGL(temporal_taps_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, ipdm_stream(stream), x, out,
                      (long long)total, S, T_in, T_out, mode);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_trilinear_f32(const float* x, float* out, int planes, int in_d, int in_h, int in_w, int out_d, int out_h,
+                                  int out_w, int accumulate, int act, void* stream) {
+  IPDM_REQUIRE(planes >= 0 && in_d > 0 && in_h > 0 && in_w > 0 && out_d > 0 && out_h > 0 && out_w > 0);
+  if (planes == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && out && x != out);
+  const float sd = out_d > 1 ? (float)(in_d - 1) / (float)(out_d - 1) : 0.f;
+  const float sh = out_h > 1 ? (float)(in_h - 1) / (float)(out_h - 1) : 0.f;
+  const float sw = out_w > 1 ? (float)(in_w - 1) / (float)(out_w - 1) : 0.f;
+  const int64_t total = (int64_t)planes * out_d * out_h * out_w;
+  hipLaunchKernelGGL(trilinear_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, ipdm_stream(stream), x, out,
+                     (long long)total, in_d, in_h, in_w, out_d, out_h, out_w, sd, sh, sw, accumulate, act);
   return ipdm_launch_status();
 }

@@ -117,6 +117,41 @@ class Downsample(nn.Module):
         return self.Conv2d_0(x)
 
 
+class ResnetBlockDDPMpp(nn.Module):
+    """ResBlock adapted from DDPM (mirror of the reference's ``models/layerspp.py:166-209``): GroupNorm+act -> conv3x3
+    -> + Dense(act(temb)) -> GroupNorm+act -> (dropout: identity when sampling) -> conv3x3, shortcut through NIN (or a
+    3x3 convolution) when the channel count changes; same parameter names."""
+
+    def __init__(self, act, in_ch, out_ch=None, temb_dim=None, conv_shortcut=False, dropout=0.1, skip_rescale=False,
+                 init_scale=0.):
+        super().__init__()
+        out_ch = out_ch if out_ch else in_ch
+        self.GroupNorm_0 = GroupNorm(num_groups=_groups(in_ch), num_channels=in_ch, eps=1e-6)
+        self.Conv_0 = conv3x3(in_ch, out_ch)
+        if temb_dim is not None:
+            self.Dense_0 = layers.Linear(temb_dim, out_ch)
+        self.GroupNorm_1 = GroupNorm(num_groups=_groups(out_ch), num_channels=out_ch, eps=1e-6)
+        self.Conv_1 = conv3x3(out_ch, out_ch, init_scale=init_scale)
+        if in_ch != out_ch:
+            if conv_shortcut:
+                self.Conv_2 = conv3x3(in_ch, out_ch)
+            else:
+                self.NIN_0 = NIN(in_ch, out_ch)
+        self.skip_rescale, self.act, self.out_ch, self.conv_shortcut = skip_rescale, act, out_ch, conv_shortcut
+
+    def forward(self, x, temb=None):
+        code = self.act.code
+        h = self.Conv_0(self.GroupNorm_0(x, code))
+        if temb is not None:
+            t = self.Dense_0(temb, act_in=code)
+            shift = torch.stack([torch.zeros_like(t), torch.ones_like(t), t], dim=-1).contiguous()
+            h = ops.affine_act(h, shift, ops.ACT_NONE, out=h)
+        h = self.Conv_1(self.GroupNorm_1(h, code))
+        if x.shape[1] != self.out_ch:
+            x = self.Conv_2(x) if self.conv_shortcut else self.NIN_0(x)
+        return _skip(x, h, self.skip_rescale)
+
+
 class ResnetBlockBigGANpp(nn.Module):
     def __init__(self, act, in_ch, out_ch=None, temb_dim=None, up=False, down=False, dropout=0.1, fir=False,
                  fir_kernel=(1, 3, 3, 1), skip_rescale=True, init_scale=0.):

@@ -1,7 +1,7 @@
 """NCSN++ score network (mirror of the reference's ``models/ncsnpp.py:34-381``): same constructor, the same
 ``all_modules`` ModuleList order (so state-dict keys ``all_modules.N.*`` line up), same forward control flow.
-BigGAN residual blocks with FIR resampling (upfirdn2d), GroupNorm+SiLU, attention, progressive input/output
-pyramids; every tensor op is a libipdm.so launch."""
+BigGAN or DDPM residual blocks, FIR / nearest / average resampling (upfirdn2d) with or without the resampling
+convolution, GroupNorm+SiLU, attention, progressive input/output pyramids; every tensor op is a libipdm.so launch."""
 import functools
 
 import numpy as np
@@ -12,6 +12,7 @@ from . import utils, layers, layerspp
 from .. import ops
 
 ResnetBlockBigGAN = layerspp.ResnetBlockBigGANpp
+ResnetBlockDDPM = layerspp.ResnetBlockDDPMpp
 Combine = layerspp.Combine
 conv3x3 = layerspp.conv3x3
 get_act = layers.get_act
@@ -45,11 +46,13 @@ class NCSNpp(nn.Module):
         assert progressive in ['none', 'output_skip', 'residual']
         assert progressive_input in ['none', 'input_skip', 'residual']
         assert embedding_type in ['fourier', 'positional']
-        if resblock_type != 'biggan' or progressive == 'residual':
-            raise NotImplementedError("built: BigGAN blocks with progressive in {none, output_skip} and progressive_input in "
-                                      "{none, input_skip, residual} (every shipped configs/ve NCSN++ config); the 'ddpm' "
-                                      "block type and the 'residual' output pyramid (whose fir up-sampling convolution raises "
-                                      "in the reference itself, up_or_down_sampling.py:126) are not")
+        if resblock_type not in ('biggan', 'ddpm'):
+            raise ValueError(f'resblock type {resblock_type} unrecognized.')
+        if progressive == 'residual':
+            raise NotImplementedError("the 'residual' OUTPUT pyramid is not built: its fir up-sampling convolution "
+                                      "(up_or_down_sampling.upsample_conv_2d) raises in the reference itself "
+                                      "(up_or_down_sampling.py:126), and no shipped config selects it")
+        resamp_with_conv = config.model.resamp_with_conv
         combiner = functools.partial(Combine, method=config.model.progressive_combine.lower())
 
         modules = []
@@ -70,8 +73,14 @@ class NCSNpp(nn.Module):
             self.pyramid_downsample = layerspp.Downsample(fir=fir, fir_kernel=fir_kernel, with_conv=False)
         elif progressive_input == 'residual':
             pyramid_downsample = functools.partial(layerspp.Downsample, fir=fir, fir_kernel=fir_kernel, with_conv=True)
-        ResnetBlock = functools.partial(ResnetBlockBigGAN, act=act, dropout=dropout, fir=fir, fir_kernel=fir_kernel,
-                                        init_scale=init_scale, skip_rescale=skip_rescale, temb_dim=nf * 4)
+        if resblock_type == 'ddpm':
+            ResnetBlock = functools.partial(ResnetBlockDDPM, act=act, dropout=dropout, init_scale=init_scale,
+                                            skip_rescale=skip_rescale, temb_dim=nf * 4)
+            Upsample = functools.partial(layerspp.Upsample, with_conv=resamp_with_conv, fir=fir, fir_kernel=fir_kernel)
+            Downsample = functools.partial(layerspp.Downsample, with_conv=resamp_with_conv, fir=fir, fir_kernel=fir_kernel)
+        else:
+            ResnetBlock = functools.partial(ResnetBlockBigGAN, act=act, dropout=dropout, fir=fir, fir_kernel=fir_kernel,
+                                            init_scale=init_scale, skip_rescale=skip_rescale, temb_dim=nf * 4)
 
         channels = config.data.num_channels
         input_pyramid_ch = channels
@@ -87,7 +96,7 @@ class NCSNpp(nn.Module):
                     modules.append(AttnBlock(channels=in_ch))
                 hs_c.append(in_ch)
             if i_level != num_resolutions - 1:
-                modules.append(ResnetBlock(down=True, in_ch=in_ch))
+                modules.append(Downsample(in_ch=in_ch) if resblock_type == 'ddpm' else ResnetBlock(down=True, in_ch=in_ch))
                 if progressive_input == 'input_skip':
                     modules.append(combiner(dim1=input_pyramid_ch, dim2=in_ch))
                     if config.model.progressive_combine.lower() == 'cat':
@@ -113,7 +122,7 @@ class NCSNpp(nn.Module):
                 modules.append(GroupNorm(num_groups=min(in_ch // 4, 32), num_channels=in_ch, eps=1e-6))
                 modules.append(conv3x3(in_ch, channels, bias=True, init_scale=init_scale))
             if i_level != 0:
-                modules.append(ResnetBlock(in_ch=in_ch, up=True))
+                modules.append(Upsample(in_ch=in_ch) if resblock_type == 'ddpm' else ResnetBlock(in_ch=in_ch, up=True))
         assert not hs_c
         if progressive != 'output_skip':
             modules.append(GroupNorm(num_groups=min(in_ch // 4, 32), num_channels=in_ch, eps=1e-6))
@@ -157,7 +166,7 @@ class NCSNpp(nn.Module):
                     m_idx += 1
                 hs.append(h)
             if i_level != self.num_resolutions - 1:
-                h = modules[m_idx](hs[-1], temb)
+                h = modules[m_idx](hs[-1]) if self.resblock_type == 'ddpm' else modules[m_idx](hs[-1], temb)
                 m_idx += 1
                 if self.progressive_input == 'input_skip':
                     input_pyramid = self.pyramid_downsample(input_pyramid)
@@ -196,7 +205,7 @@ class NCSNpp(nn.Module):
                     pyramid = modules[m_idx](pyramid_h, residual=self.pyramid_upsample(pyramid))
                 m_idx += 1
             if i_level != 0:
-                h = modules[m_idx](h, temb)
+                h = modules[m_idx](h) if self.resblock_type == 'ddpm' else modules[m_idx](h, temb)
                 m_idx += 1
         assert not hs
         if self.progressive == 'output_skip':

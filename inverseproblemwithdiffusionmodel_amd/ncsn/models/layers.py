@@ -217,7 +217,7 @@ class MSFBlock(nn.Module):
         self.features = features
 
     def forward(self, xs, shape, act_out=ops.ACT_NONE):
-        """sum_i bilinear(conv_i(xs[i]));  act_out: return act(sum) instead (all the following CRP block needs)"""
+        """sum_i bilinear (3-D: trilinear) (conv_i(xs[i]));  act_out: return act(sum) instead (all the following CRP block needs)"""
         shape = tuple(int(s) for s in shape)
         sums = None
         n = len(self.convs)
@@ -229,10 +229,9 @@ class MSFBlock(nn.Module):
                 else:
                     sums = conv(xs[i], residual=sums)
             else:
-                if xs[i].dim() == 5:
-                    raise NotImplementedError("trilinear resize: NCSN3DShallow only ever fuses equal-sized volumes")
                 h = conv(xs[i])
-                sums = ops.bilinear(h, shape, out=sums, accumulate=sums is not None, act=last_act)
+                resize = ops.trilinear if h.dim() == 5 else ops.bilinear
+                sums = resize(h, shape, out=sums, accumulate=sums is not None, act=last_act)
         return sums
 
 

@@ -443,6 +443,18 @@ def bilinear(x, size, out=None, accumulate=False, act=ACT_NONE):
     return out
 
 
+def trilinear(x, size, out=None, accumulate=False, act=ACT_NONE):
+    """F.interpolate(x, size, mode='trilinear', align_corners=True) of (B, C, D, H, W), optionally accumulated into out"""
+    x = _gpu(x, torch.float32, "x")
+    B, C, D, H, W = x.shape
+    od, oh, ow = (int(v) for v in size)
+    if out is None:
+        out = torch.empty((B, C, od, oh, ow), dtype=torch.float32, device=x.device)
+        accumulate = False
+    call("ipdm_trilinear_f32", _ptr(x), _ptr(out), B * C, D, H, W, od, oh, ow, int(bool(accumulate)), act, _stream())
+    return out
+
+
 # ---- NCSN++ / predictor-corrector extras --------------------------------------------------------
 def groupnorm_coef(x, weight, bias, groups, eps=1e-6):
     x = _gpu(x, torch.float32, "x")

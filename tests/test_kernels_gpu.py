@@ -516,6 +516,42 @@ def test_bilinear(ops, ish, osh):
         assert torch.equal(got, x)                               # identity resize is exact
 
 
+@pytest.mark.parametrize("ish,osh", [((3, 4, 5), (6, 8, 10)), ((8, 8, 12), (8, 8, 24)), ((4, 4, 6), (4, 4, 6)),
+                                     ((2, 5, 7), (5, 11, 9)), ((1, 1, 1), (2, 3, 4)), ((8, 8, 24), (8, 8, 12))])
+def test_trilinear(ops, ish, osh):
+    """F.interpolate(mode='trilinear', align_corners=True) of the 3-D MSF block (layers3d.py:185,214), plain and accumulated"""
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 3, *ish, generator=gen)
+    acc = torch.randn(2, 3, *osh, generator=gen)
+    want = F.interpolate(x.double(), size=osh, mode="trilinear", align_corners=True)
+    got = ops.trilinear(x.cuda(), osh).cpu()
+    assert (got.double() - want).abs().max() < 2e-5                  # fp32 source coordinates, as in ATen's fp32 path
+    assert (got - F.interpolate(x, size=osh, mode="trilinear", align_corners=True)).abs().max() < 2e-6
+    out = acc.clone().cuda()
+    ops.trilinear(x.cuda(), osh, out=out, accumulate=True, act=ops.ACT_ELU)
+    assert (out.cpu().double() - F.elu(acc.double() + want)).abs().max() < 2e-5
+    if ish == osh:
+        assert torch.equal(got, x)                               # identity resize is exact
+
+
+def test_msf_block_3d_unequal_volumes(ops):
+    """3-D MSF block on volumes of different sizes: sum_i trilinear(conv3d_i(x_i)) against torch"""
+    from inverseproblemwithdiffusionmodel_amd.ncsn.models import layers3d
+    gen = torch.Generator().manual_seed(14)
+    msf = layers3d.MSFBlock([16, 16], 16).cuda()
+    for p_ in msf.parameters():
+        p_.data = (0.1 * torch.randn(p_.shape, generator=gen)).cuda()
+    xs = [torch.randn(2, 16, 4, 4, 12, generator=gen), torch.randn(2, 16, 4, 4, 6, generator=gen)]
+    shape = (4, 4, 12)
+    with torch.no_grad():
+        got = msf([v.cuda() for v in xs], shape).cpu().double()
+        want = 0
+        for conv, v in zip(msf.convs, xs):
+            h = F.conv3d(v.double(), conv.weight.detach().cpu().double(), conv.bias.detach().cpu().double(), padding=1)
+            want = want + F.interpolate(h, size=shape, mode="trilinear", align_corners=True)
+    assert (got - want).abs().max() <= 2e-5 * want.abs().max()
+
+
 # ---- MFMA convolution ---------------------------------------------------------------------------
 CONV_CASES = [
     # B, Cin, Cout, H, W, k, dil, fused-norm, act, residual
