@@ -189,6 +189,16 @@ int ipdm_add_f32(const float* x, const float* y, float* out, int64_t n, void* st
 /* out[b,...] = x[b,...] / sigmas[labels[b]];  labels == NULL: out[b,...] = x[b,...] / sigmas[b] */
 int ipdm_div_sigma_f32(const float* x, const float* sigmas, const int64_t* labels, float* out,
                        int B, int64_t sample_elems, void* stream);
+/* 3x3 'same' convolution (stride 1, dilation 1, zero padding) with at most three input OR at most three output channels:
+ * the first / last layer of every score network (nn.Conv2d begin_conv / end_conv, ncsn/models/ncsnv2.py:40,45; conv3x3 of
+ * models/ncsnpp.py:143,226).  Streaming fp32 kernels on the vector ALU (the matrix-core kernels pad the thin side to an
+ * MFMA operand): w is the reference's own layout [Cout][Cin][3][3], bias may be NULL; W % 4 == 0, 16-byte aligned x / out.
+ * ipdm_conv3x3_thin_supported tells whether a shape is served (else IPDM_EUNSUPPORTED). */
+int ipdm_conv3x3_thin_supported(int Cin, int Cout, int H, int W);
+int ipdm_conv3x3_thin_f32(const float* x, const float* w, const float* bias,
+                          const float* coef /* NULL, or [B][Cin][3] = (c0, c1, c2): the input is (x - c0) * c1 + c2 inside the
+                                               image (few-input-channel form only: `h = 2x - 1`, ncsnv2.py:64) */,
+                          float* out, int B, int Cin, int Cout, int H, int W, void* stream);
 /* MaxPool2d(kernel 5, stride 1, padding 2) on [planes][H][W] */
 int ipdm_maxpool5_f32(const float* x, float* y, int planes, int H, int W, void* stream);
 /* 2x2 mean pooling (ConvMeanPool's tail) [planes][H][W] -> [planes][H/2][W/2]; H, W even */

@@ -48,6 +48,8 @@ SIGNATURES = {
     "ipdm_maxpool5_f32": [P, P, c_int, c_int, c_int, P],
     "ipdm_meanpool2_f32": [P, P, c_int, c_int, c_int, P],
     "ipdm_bilinear_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "ipdm_conv3x3_thin_supported": [c_int, c_int, c_int, c_int],
+    "ipdm_conv3x3_thin_f32": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "ipdm_trilinear_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "ipdm_groupnorm_coef_f32": [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     "ipdm_linear_f32": [P, P, P, P, c_int, c_int, c_int, c_int, P],

@@ -85,6 +85,11 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
 
     def forward(self, x, coef=None, act=ops.ACT_NONE, residual=None, out=None, act_out=ops.ACT_NONE, raw=True):
         bias = None if self.bias is None else self.bias.data
+        if (self.ndim == 2 and self.kernel_size == 3 and self.dilation == 1 and act == ops.ACT_NONE
+                and residual is None and out is None and act_out == ops.ACT_NONE and raw and x.dim() == 4
+                and (self.in_planes <= 3 or (self.out_planes <= 3 and coef is None))
+                and ops.conv3x3_thin_ok(self.in_planes, self.out_planes, x.shape[2], x.shape[3])):
+            return ops.conv3x3_thin(x, self.weight.data, bias, coef)   # first / last layer: streaming kernels
         if (USE_WINOGRAD and ops.CONV_IMPL == "f32" and self.ndim == 2 and self.kernel_size == 3 and coef is None and act == ops.ACT_NONE
                 and out is None
                 and ops.conv_wino_supported(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation)):

@@ -643,6 +643,38 @@ def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1,
     return (out, out_act) if want_act else out
 
 
+USE_THIN_CONV = os.environ.get("IPDM_THIN_CONV", "1") != "0"
+
+
+def conv3x3_thin_ok(Cin, Cout, H, W):
+    """3x3, dilation 1, no fused input norm / residual / second output, and a thin side: the streaming kernels"""
+    return USE_THIN_CONV and bool(_lib.lib.ipdm_conv3x3_thin_supported(int(Cin), int(Cout), int(H), int(W)))
+
+
+def conv3x3_thin(x, weight, bias=None, coef=None):
+    """first / last layer of a score network: x [B,Cin,H,W], weight [Cout,Cin,3,3] (the reference's layout), Cin <= 3 or
+    Cout <= 3; coef [B,Cin,3]: input affine (x - c0) * c1 + c2 inside the image (Cin <= 3 form)"""
+    x = _gpu(x, torch.float32, "x")
+    weight = _gpu(weight, torch.float32, "weight")
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    if tuple(weight.shape) != (Cout, Cin, 3, 3):
+        raise ValueError(f"conv3x3_thin: weight {tuple(weight.shape)} does not match input channels {Cin}")
+    out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+    if CONV_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    if coef is not None:
+        coef = _gpu(coef, torch.float32, "coef")
+        if tuple(coef.shape) != (B, Cin, 3):
+            raise ValueError(f"conv3x3_thin: coef {tuple(coef.shape)} != {(B, Cin, 3)}")
+    call("ipdm_conv3x3_thin_f32", _ptr(x), _ptr(weight), _ptr(bias), _ptr(coef), _ptr(out), B, Cin, Cout, H, W, _stream())
+    if CONV_TRACE is not None:
+        e1.record()
+        CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=1, res=False, n_out=1, e0=e0, e1=e1, thin=True))
+    return out
+
+
 # ---- convolution on the bf16 matrix cores (exact three-way split) ---------------------------------------------
 # Which kernel family the modules use (conv_weight()):
 #   "bx3" (default): fp32-faithful split-bf16 kernels (conv_bx3.hip) -- 2.67x the fp32 MFMA rate

@@ -552,6 +552,45 @@ def test_msf_block_3d_unequal_volumes(ops):
     assert (got - want).abs().max() <= 2e-5 * want.abs().max()
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(3, 1, 128, 32, 32), (2, 2, 20, 12, 16), (2, 3, 128, 16, 32), (1, 1, 5, 1, 4),
+                                            (3, 128, 1, 32, 32), (2, 24, 2, 12, 16), (2, 128, 3, 16, 32), (1, 7, 1, 1, 4),
+                                            (2, 1, 1, 8, 8), (2, 3, 3, 9, 12), (2, 16, 1, 6, 512), (1, 16, 2, 5, 24)])
+def test_conv3x3_thin(ops, B, Cin, Cout, H, W):
+    """first / last layer streaming kernels (begin_conv / end_conv, ncsnv2.py:40,45) against a float64 convolution; the
+    matrix-core path must agree to rounding"""
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.2
+    b = torch.randn(Cout, generator=gen)
+    assert ops.conv3x3_thin_ok(Cin, Cout, H, W)
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    got = ops.conv3x3_thin(x.cuda(), w.cuda(), b.cuda()).cpu().double()
+    assert (got - want).abs().max() <= 2e-6 * max(1.0, want.abs().max())
+    got_nb = ops.conv3x3_thin(x.cuda(), w.cuda(), None).cpu().double()
+    assert (got_nb - F.conv2d(x.double(), w.double(), None, padding=1)).abs().max() <= 2e-6 * max(1.0, want.abs().max())
+    mfma = ops.conv2d(x.cuda(), ops.conv_weight(w.cuda()), b.cuda()).cpu().double()
+    assert (mfma - got).abs().max() <= 4e-6 * max(1.0, want.abs().max())
+    if Cin <= 3:                                              # fused input affine: padding stays zero
+        coef = torch.randn(B, Cin, 3, generator=gen)
+        xa = (x - coef[:, :, 0, None, None]) * coef[:, :, 1, None, None] + coef[:, :, 2, None, None]
+        want_a = F.conv2d(xa.double(), w.double(), b.double(), padding=1)
+        got_a = ops.conv3x3_thin(x.cuda(), w.cuda(), b.cuda(), coef.cuda()).cpu().double()
+        assert (got_a - want_a).abs().max() <= 4e-6 * max(1.0, want_a.abs().max())
+    # a sample's result does not depend on the batch around it
+    if B > 1:
+        one = ops.conv3x3_thin(x[1:2].cuda(), w.cuda(), b.cuda()).cpu()
+        assert torch.equal(one, ops.conv3x3_thin(x.cuda(), w.cuda(), b.cuda()).cpu()[1:2])
+
+
+def test_conv3x3_thin_unsupported(ops):
+    from inverseproblemwithdiffusionmodel_amd import _lib
+    assert not ops.conv3x3_thin_ok(16, 16, 32, 32) and not ops.conv3x3_thin_ok(1, 16, 32, 30)
+    x = torch.randn(1, 16, 8, 8).cuda()
+    w = torch.randn(16, 16, 3, 3).cuda()
+    with pytest.raises(_lib.IpdmUnsupported):
+        ops.conv3x3_thin(x, w)
+
+
 # ---- MFMA convolution ---------------------------------------------------------------------------
 CONV_CASES = [
     # B, Cin, Cout, H, W, k, dil, fused-norm, act, residual
