@@ -324,6 +324,19 @@ int ipdm_conv2d_wino_bx3_supported(int Cin, int Cout, int H, int W, int dilation
 int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
                              float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
                              int pool2, void* stream);
+/* The same launch with the statistics epilogue: besides the result it writes, per (image, output channel), P partials
+ * (count, mean, sum of squared deviations about that mean) of the stored result -- one per (tile block, tile group), a
+ * function of the image geometry only -- to stats [B][Cout][P][3]; ipdm_instnorm_plus_coef_partials_f32 turns them into the
+ * InstanceNorm++ coefficients of the FOLLOWING normalisation (normalization.py:163-176) without reading the tensor again.
+ * ipdm_conv2d_wino_bx3_stats_partials returns P for a layer shape, 0 where the epilogue does not exist (small / dilated
+ * images, W % 4 != 0): callers then use ipdm_instnorm_plus_coef_f32 on the tensor as before. */
+int ipdm_conv2d_wino_bx3_stats_partials(int Cin, int Cout, int H, int W, int dilation, int pool2);
+int ipdm_conv2d_wino_bx3_stats_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
+                                   float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
+                                   int pool2, float* stats, void* stream);
+int ipdm_instnorm_plus_coef_partials_f32(const float* partials, int P, const float* alpha, const float* gamma,
+                                         const float* beta /* may be NULL */, float* coef /* [B][C][3] */, int B, int C,
+                                         void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Segmentation-likelihood guidance (reference: ncsn/models/__init__.py:197-215 compute_seg_grad through a MONAI UNet --

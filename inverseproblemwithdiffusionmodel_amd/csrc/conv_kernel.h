@@ -53,6 +53,10 @@ struct ConvArgs {
                              //   layers.py:291-313) to out / out_act [B][Cout][H/2][W/2]; residual is at that size too
   int ksplit = 1;            // conv_bx3 only: the K (input channel x depth tap) chunks are dealt to ksplit workgroups
   float* partial = nullptr;  //   per tile, each writing its raw partial sums to partial[ks][B][Cout][D*H*W]
+  float* stats = nullptr;    // conv_wino_bx3 wide kernel (16 x 4 tile block, 16-byte DMA) only: per-plane statistics of
+                             //   the RESULT as deterministic partials [B][Cout][P][3] = (count, mean, sum of squared
+                             //   deviations) per (tile block, tile group), P = 2 * tiles_y * tiles_x -- what the following
+                             //   InstanceNorm++ needs, so that it does not read the tensor again
 };
 
 // NCT x NPT MFMA tiles per wave, WCO x WPX waves (WCO*WPX == 4), PW = pixel-tile width (16 or 32),

@@ -455,7 +455,19 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
 // pixels (a quad is then entirely inside or entirely outside the image, so the range check still pads), 25-27
 // wave-instructions per chunk and workgroup instead of 96 -- an LDS-DMA instruction costs ~100 issue cycles next to
 // MFMAs, whatever its width.
-template <int TX, int TY, bool CO_MAJOR, bool DMA4, bool POOL = false>
+// sum over the 32 lanes of a half-wave, the total in every lane: four DPP adds inside the 16-lane rows (quad swaps, then the
+// half-row and row mirrors) and one cross-row exchange -- a fixed order, and a fifth of the latency of five bpermutes
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
+  return v + __shfl_xor(v, 16, 64);
+}
+
+// STATS: the epilogue also reduces every (channel, tile group) of the workgroup's tile block to (count, mean, sum of squared
+// deviations) of the stored result and writes them to a.stats (own instantiation, same reason as POOL).
+template <int TX, int TY, bool CO_MAJOR, bool DMA4, bool POOL = false, bool STATS = false>
 __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int total_tiles) {
   constexpr int QC = TX / 2 + 2, RC4 = 4 * QC;               // quads / floats per raw row (x0-4 .. x0+2TX+3)
   constexpr int QN = (2 * TY + 2) * QC;                       // quads per channel
@@ -791,6 +803,14 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
         }
       __syncthreads();
       if constexpr (AHEAD && rnd < 3) prefetch(std::integral_constant<int, rnd + 1>{});
+      constexpr int NSV = POOL ? 1 : 4;
+      [[maybe_unused]] float sv[2][NSV];                      // STATS: this thread's stored values of the round
+      if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int k = 0; k < NSV; ++k) sv[i][k] = 0.f;
+      }
       if (in_range(tg)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -813,6 +833,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
             float v = (((y00 + y10) + y01) + y11) * 0.25f;
             const size_t o = out_index(c, tg, i, 0);
             if (has_res) v += resv[bf][i][0].x;
+            if constexpr (STATS) sv[i][0] = v;
             if (a.out) a.out[o] = v;
             if (a.out_act) a.out_act[o] = a.act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, a.act_out);
           } else {
@@ -825,6 +846,10 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
               y0v += resv[bf][i][ii].x;
               y1v += resv[bf][i][ii].y;
             }
+            if constexpr (STATS) {
+              sv[i][2 * ii] = y0v;
+              sv[i][2 * ii + 1] = y1v;
+            }
             if (a.out) *reinterpret_cast<float2*>(a.out + o) = make_float2(y0v, y1v);
             if (a.out_act) {
               const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
@@ -832,6 +857,41 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
               *reinterpret_cast<float2*>(a.out_act + o) = make_float2(e0, e1);
             }
           }
+          }
+        }
+      }
+      if constexpr (STATS) {
+        // the 32 lanes of a half-wave hold the 32 tiles of tile group tg for channels 2*ecg, 2*ecg+1: count / mean / sum of
+        // squared deviations about that mean, reduced by butterflies (fixed order -> deterministic), one partial per
+        // (image, channel, tile block, tile group)
+        const bool inr = in_range(tg);
+        const unsigned long long bal = __ballot(inr);
+        const float cnt = (float)(NSV * __popcll(h ? (bal >> 32) : (bal & 0xffffffffull)));
+        const int tiles_img = a.tiles_x * a.tiles_y;
+        const int tb = (cur_g.y0 / (2 * TY)) * a.tiles_x + cur_g.x0 / (2 * TX);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          // one pass: sums of (v - K) and (v - K)^2 about a shift K taken FROM the data (the first lane's first value of
+          // this half-wave), so that the subtraction below cancels nothing the spread of the data does not
+          const float k0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv[i][0]), 0));
+          const float k1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv[i][0]), 32));
+          const float K = h ? k1 : k0;
+          float s1 = 0.f, s2 = 0.f;
+          if (inr) {
+#pragma unroll
+            for (int k = 0; k < NSV; ++k) {
+              const float dlt = sv[i][k] - K;
+              s1 += dlt;
+              s2 += dlt * dlt;
+            }
+          }
+          s1 = half_wave_sum(s1);
+          s2 = half_wave_sum(s2);
+          if (etile == 0) {
+            const int co = co0 + c * 32 + ecg * 2 + i;
+            float* sp = a.stats + ((((size_t)cur_g.b * a.Cout + co) * tiles_img + tb) * 2 + tg) * 3;
+            const float dm = cnt > 0.f ? s1 / cnt : 0.f;
+            sp[0] = cnt; sp[1] = K + dm; sp[2] = fmaxf(s2 - s1 * dm, 0.f);
           }
         }
       }
@@ -1261,7 +1321,9 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
                              reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, true>),
                              reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, true>),
                              reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, false, true>),
-                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, true, true>)};
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, true, true>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, true, false, true>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, true, true, true>)};
     for (const void* k : kernels) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS_BYTES);
       if (e != hipSuccess) return (int)e;
@@ -1276,7 +1338,7 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
     const char* e = getenv("IPDM_WBX3_C128");
     use_c128 = e ? atoi(e) : 0;
   }
-  if (use_c128 && !a.pool2 && wino_persist() && a.Cout % 128 == 0 && a.Cin >= 2 * X_KC && (small_dma || !small)) {
+  if (use_c128 && !a.pool2 && !a.stats && wino_persist() && a.Cout % 128 == 0 && a.Cin >= 2 * X_KC && (small_dma || !small)) {
     // 128 channels x 32 tiles per workgroup: 16 x 2 tiles (4 x 32 pixels) on wide images, 8 x 4 (8 x 16) on small ones
     static bool attr2 = false;
     if (!attr2) {
@@ -1313,6 +1375,7 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
     dma4_ok = e ? atoi(e) : 1;
   }
   const bool dma4 = dma4_ok && a.W % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
+  if (a.stats && (small || !wino_persist() || a.Cin < 2 * X_KC)) return IPDM_EUNSUPPORTED;
   if (small_dma) {
     if (dma4)
       hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<8, 8, true, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
@@ -1321,6 +1384,14 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
   } else if (small) {
     hipLaunchKernelGGL(conv_wino_bx3_kernel<true>, dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
   } else if (wino_persist() && a.Cin >= 2 * X_KC) {
+    if (a.stats) {
+      if (!dma4) return IPDM_EUNSUPPORTED;
+      if (a.pool2)
+        hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false, true, true, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+      else
+        hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false, true, false, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+      return ipdm_launch_status();
+    }
     if (a.pool2 && dma4)
       hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false, true, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
     else if (a.pool2)
@@ -1364,9 +1435,9 @@ extern "C" int ipdm_conv2d_wino_bx3_supported(int Cin, int Cout, int H, int W, i
   return wino_bx3_ok(a, 3) ? 1 : 0;
 }
 
-extern "C" int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const float* bias, const float* residual,
-                                        float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H, int W,
-                                        int dilation, int pool2, void* stream) {
+static int wino_bx3_entry(const float* x, const void* U, const float* bias, const float* residual, float* out,
+                          float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation, int pool2,
+                          float* stats, void* stream) {
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && dilation >= 1);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && U && (out || out_act) && x != out && x != out_act);
@@ -1375,6 +1446,31 @@ extern "C" int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const flo
   a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = dilation; a.act = IPDM_ACT_NONE;
   a.D = 1; a.kd = 1; a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
   a.pool2 = pool2 ? 1 : 0;
+  a.stats = stats;
   if (!wino_bx3_ok(a, 3)) return IPDM_EUNSUPPORTED;
   return conv_wino_bx3_launch(a, ipdm_stream(stream));
+}
+
+extern "C" int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const float* bias, const float* residual,
+                                        float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H, int W,
+                                        int dilation, int pool2, void* stream) {
+  return wino_bx3_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, pool2, nullptr, stream);
+}
+
+// partials per plane the statistics epilogue writes for this layer shape (0: that epilogue does not serve it)
+extern "C" int ipdm_conv2d_wino_bx3_stats_partials(int Cin, int Cout, int H, int W, int dilation, int pool2) {
+  ConvArgs a;
+  a.coef = nullptr; a.act = IPDM_ACT_NONE; a.dil = dilation; a.D = 1; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.B = 1;
+  a.pool2 = pool2 ? 1 : 0;
+  if (!wino_bx3_ok(a, 3) || x_small(a) || !wino_persist() || Cin < 2 * X_KC || W % 4 != 0) return 0;
+  if (pool2 && (H % 2 || W % 2)) return 0;
+  return 2 * ((W + 2 * X_TX - 1) / (2 * X_TX)) * ((H + 2 * X_TY - 1) / (2 * X_TY));
+}
+
+extern "C" int ipdm_conv2d_wino_bx3_stats_f32(const float* x, const void* U, const float* bias, const float* residual,
+                                              float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H,
+                                              int W, int dilation, int pool2, float* stats, void* stream) {
+  IPDM_REQUIRE(stats != nullptr);
+  if (ipdm_conv2d_wino_bx3_stats_partials(Cin, Cout, H, W, dilation, pool2) == 0) return IPDM_EUNSUPPORTED;
+  return wino_bx3_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, pool2, stats, stream);
 }

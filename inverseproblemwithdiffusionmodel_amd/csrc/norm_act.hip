@@ -112,6 +112,46 @@ __global__ __launch_bounds__(256) void instnorm_plus_coef_kernel(float* __restri
   }
 }
 
+// pass 1 from the producing convolution's epilogue partials ([B][C][P][3] = count, mean, sum of squared deviations per tile
+// group): per plane, the partials are merged in index order with the pooled-variance update (exact in real arithmetic,
+// float64 here), giving the same (mean, 1/sqrt(biased var + 1e-5)) plane_stats_kernel writes -- without reading the tensor
+__global__ __launch_bounds__(256) void plane_stats_from_partials_kernel(const float* __restrict__ part, float* __restrict__ coef,
+                                                                        int planes, int P) {
+  // one wave per plane: lane l merges partials l, l+64, ... in order, then a butterfly merges the 64 lanes (the pairwise
+  // update is symmetric, so every lane ends with the same triple): a fixed tree, whatever the batch
+  const int lane = threadIdx.x & 63;
+  const int pl = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pl >= planes) return;
+  const float* pp = part + (size_t)pl * P * 3;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int i = lane; i < P; i += 64) {
+    const double nb = pp[i * 3], mb = pp[i * 3 + 1], qb = pp[i * 3 + 2];
+    if (nb > 0.0) {
+      const double nn = n + nb, d = mb - mean;
+      mean += d * (nb / nn);
+      m2 += qb + d * d * (n * nb / nn);
+      n = nn;
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const double nb = __shfl_xor(n, m, 64), mb = __shfl_xor(mean, m, 64), qb = __shfl_xor(m2, m, 64);
+    const double nn = n + nb;
+    if (nn > 0.0) {
+      // symmetric form: both partners compute the same numbers
+      const double d = mb - mean;
+      const double new_mean = (n * mean + nb * mb) / nn;
+      m2 = (m2 + qb) + d * d * (n * nb / nn);
+      mean = new_mean;
+      n = nn;
+    }
+  }
+  if (lane == 0) {
+    coef[(size_t)pl * 3 + 0] = (float)mean;
+    coef[(size_t)pl * 3 + 1] = 1.0f / sqrtf((float)(m2 / n) + 1e-5f);
+  }
+}
+
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* x, const float* __restrict__ coef, float* y,
                                                          int HW, int act) {
   // grid.x = plane tiles, grid.y = planes
@@ -353,6 +393,17 @@ extern "C" int ipdm_instnorm_plus_coef_f32(const float* x, const float* alpha, c
     hipLaunchKernelGGL(plane_stats_kernel<true>, dim3(B * C), dim3(256), 0, s, x, coef, HW);
   else
     hipLaunchKernelGGL(plane_stats_kernel<false>, dim3(B * C), dim3(256), 0, s, x, coef, HW);
+  hipLaunchKernelGGL(instnorm_plus_coef_kernel, dim3(B), dim3(256), 0, s, coef, alpha, gamma, beta, C);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_instnorm_plus_coef_partials_f32(const float* partials, int P, const float* alpha, const float* gamma,
+                                                    const float* beta, float* coef, int B, int C, void* stream) {
+  IPDM_REQUIRE(B >= 0 && C > 0 && P > 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(partials && alpha && gamma && coef);
+  hipStream_t s = ipdm_stream(stream);
+  hipLaunchKernelGGL(plane_stats_from_partials_kernel, dim3((B * C + 3) / 4), dim3(256), 0, s, partials, coef, B * C, P);
   hipLaunchKernelGGL(instnorm_plus_coef_kernel, dim3(B), dim3(256), 0, s, coef, alpha, gamma, beta, C);
   return ipdm_launch_status();
 }

@@ -83,7 +83,10 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
     def packed(self):
         return self._cached("direct_" + ops.CONV_IMPL, ops.conv_weight)
 
-    def forward(self, x, coef=None, act=ops.ACT_NONE, residual=None, out=None, act_out=ops.ACT_NONE, raw=True):
+    def forward(self, x, coef=None, act=ops.ACT_NONE, residual=None, out=None, act_out=ops.ACT_NONE, raw=True,
+                want_stats=False):
+        """want_stats: the result goes into an InstanceNorm++ next (the Winograd kernel's statistics epilogue then spares
+        that normalisation its pass over the tensor; ignored by the other kernels)"""
         bias = None if self.bias is None else self.bias.data
         if (self.ndim == 2 and self.kernel_size == 3 and self.dilation == 1 and act == ops.ACT_NONE
                 and residual is None and out is None and act_out == ops.ACT_NONE and raw and x.dim() == 4
@@ -99,7 +102,7 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
                 and act == ops.ACT_NONE and out is None and ops.wino_bx3_pays(self.in_planes, self.out_planes, x.shape[2],
                                                                               x.shape[3], self.dilation)):
             return ops.conv2d_wino_bx3(x, self.packed_wino_bx3(), bias, residual, act_out=act_out, raw=raw,
-                                       dilation=self.dilation)
+                                       dilation=self.dilation, want_stats=want_stats)
         if self.ndim == 3:
             return ops.conv3d(x, self.packed(), bias, coef, act, residual, self.dilation, act_out=act_out, raw=raw)
         return ops.conv2d(x, self.packed(), bias, coef, act, residual, self.dilation, out=out, act_out=act_out, raw=raw)
@@ -150,7 +153,7 @@ class ConvMeanPool(nn.Module):
             return None
         try:
             return ops.conv2d_wino_bx3(inputs, c.packed_wino_bx3(), None if c.bias is None else c.bias.data, residual,
-                                       act_out=act_out, pool2=True)
+                                       act_out=act_out, pool2=True, want_stats=True)     # a block's result: normalised next
         except _lib.IpdmUnsupported:
             return None
 
@@ -315,7 +318,7 @@ class ResidualBlock(nn.Module):
     def forward(self, x, want_act=False):
         """norm -> act -> conv1 -> norm -> act -> conv2 (+ shortcut).  want_act: also return act(out)."""
         code = _act_code(self.non_linearity)
-        h = self.conv1(self.normalize1(x, code))
+        h = self.conv1(self.normalize1(x, code), want_stats=True)
         a2 = self.normalize2(h, code)
         if self.output_dim == self.input_dim and self.resample is None:
             shortcut = x
@@ -327,6 +330,7 @@ class ResidualBlock(nn.Module):
                 return fused
             out = ops.add(shortcut, self.conv2(a2))
             return (out, ops.act(out, code)) if want_act else out
+        # the block's result is what the next block normalises first
         if want_act:
-            return self.conv2(a2, residual=shortcut, act_out=code)
-        return self.conv2(a2, residual=shortcut)
+            return self.conv2(a2, residual=shortcut, act_out=code, want_stats=True)
+        return self.conv2(a2, residual=shortcut, want_stats=True)

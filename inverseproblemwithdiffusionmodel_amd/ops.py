@@ -364,11 +364,21 @@ def ssim(img, ref, data_range=2.0):
 
 
 # ---- score-network glue -----------------------------------------------------------------------
+# the producing convolution's epilogue hands the plane statistics over as partials (conv2d_wino_bx3(want_stats=True) hangs
+# them on its result as `_ipdm_partials`), so that InstanceNorm++ does not read the tensor a second time
+USE_STATS_EPILOGUE = os.environ.get("IPDM_STATS_EPILOGUE", "1") != "0"
+
+
 def instnorm_plus_coef(x, alpha, gamma, beta):
     """x [B, C, *spatial] (2-D images or 3-D volumes: the statistics run over all spatial positions)"""
     x = _gpu(x, torch.float32, "x")
     B, C = x.shape[:2]
     coef = torch.empty((B, C, 3), dtype=torch.float32, device=x.device)
+    part = getattr(x, "_ipdm_partials", None)
+    if part is not None and USE_STATS_EPILOGUE and tuple(part.shape[:2]) == (B, C):
+        call("ipdm_instnorm_plus_coef_partials_f32", _ptr(part), int(part.shape[2]), _ptr(alpha), _ptr(gamma), _ptr(beta),
+             _ptr(coef), B, C, _stream())
+        return coef
     call("ipdm_instnorm_plus_coef_f32", _ptr(x), _ptr(alpha), _ptr(gamma), _ptr(beta), _ptr(coef), B, C,
          x.numel() // max(B * C, 1), _stream())
     return coef
@@ -806,10 +816,12 @@ def conv_wino_bx3_supported(Cin, Cout, H, W, dilation=1):
     return bool(_lib.lib.ipdm_conv2d_wino_bx3_supported(Cin, Cout, H, W, dilation))
 
 
-def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dilation=1, pool2=False):
+def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dilation=1, pool2=False, want_stats=False):
     """3x3 convolution through the split-bf16 Winograd kernel (same output options as conv2d).
     pool2: the ConvMeanPool form -- outputs (and the residual) are [B, Cout, H/2, W/2] 2x2 means of the convolution;
-    raises IpdmUnsupported where the pooled epilogue is not built (small / odd images)."""
+    raises IpdmUnsupported where the pooled epilogue is not built (small / odd images).
+    want_stats: the result feeds an InstanceNorm++ -- where the statistics epilogue exists for this shape, its partials
+    [B, Cout, P, 3] are hung on the raw result as `_ipdm_partials` (instnorm_plus_coef picks them up)."""
     x = _gpu(x, torch.float32, "x")
     B, Cin, H, W = x.shape
     if U.kk != 16 or U.Cin != Cin:
@@ -825,12 +837,23 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     nb = wino_bx3_max_batch(Cin, H, W, dilation)
+    part = None
+    if want_stats and raw and USE_STATS_EPILOGUE and x.data_ptr() % 16 == 0:
+        P = int(_lib.lib.ipdm_conv2d_wino_bx3_stats_partials(Cin, Cout, H, W, dilation, int(bool(pool2))))
+        if P > 0:
+            part = torch.empty((B, Cout, P, 3), dtype=torch.float32, device=x.device)
     for b0 in range(0, B, nb):           # one launch unless the batch outgrows the kernel's 32-bit buffer offsets
         b1 = min(B, b0 + nb)
-        call("ipdm_conv2d_wino_bx3_f32", _ptr(x[b0:b1]), _ptr(U.blob), _ptr(bias),
-             _ptr(None if residual is None else residual[b0:b1]), _ptr(None if out is None else out[b0:b1]),
-             _ptr(None if out_act is None else out_act[b0:b1]), act_out, b1 - b0, Cin, Cout, H, W, dilation,
-             int(bool(pool2)), _stream())
+        args = (_ptr(x[b0:b1]), _ptr(U.blob), _ptr(bias),
+                _ptr(None if residual is None else residual[b0:b1]), _ptr(None if out is None else out[b0:b1]),
+                _ptr(None if out_act is None else out_act[b0:b1]), act_out, b1 - b0, Cin, Cout, H, W, dilation,
+                int(bool(pool2)))
+        if part is not None:
+            call("ipdm_conv2d_wino_bx3_stats_f32", *args, _ptr(part[b0:b1]), _stream())
+        else:
+            call("ipdm_conv2d_wino_bx3_f32", *args, _stream())
+    if part is not None:
+        out._ipdm_partials = part
     if CONV_TRACE is not None:
         e1.record()
         CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, res=residual is not None,

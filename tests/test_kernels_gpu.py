@@ -552,6 +552,50 @@ def test_msf_block_3d_unequal_volumes(ops):
     assert (got - want).abs().max() <= 2e-5 * want.abs().max()
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,pool,res", [(2, 128, 128, 64, 64, False, True), (3, 32, 64, 40, 36, False, False),
+                                                     (2, 64, 128, 64, 32, True, True), (1, 32, 64, 34, 44, True, False),
+                                                     (2, 32, 64, 32, 32, False, True)])
+def test_wino_bx3_statistics_epilogue(ops, B, Cin, Cout, H, W, pool, res):
+    """the Winograd kernel's statistics epilogue: the InstanceNorm++ coefficients from its partials equal those from a pass
+    over the stored tensor (ragged tile blocks, pooled epilogue, residual); the result itself is bit-identical with and
+    without the epilogue"""
+    from inverseproblemwithdiffusionmodel_amd import _lib
+    gen = torch.Generator().manual_seed(41)
+    x = torch.randn(B, Cin, H, W, generator=gen).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.1).cuda()
+    b = torch.randn(Cout, generator=gen).cuda()
+    oh, ow = (H // 2, W // 2) if pool else (H, W)
+    r = (torch.randn(B, Cout, oh, ow, generator=gen) * 3 + 5).cuda() if res else None      # a mean far from zero
+    U = ops.conv_wino_bx3_weight(w)
+    P = int(_lib.lib.ipdm_conv2d_wino_bx3_stats_partials(Cin, Cout, H, W, 1, int(pool)))
+    assert P == 2 * ((W + 31) // 32) * ((H + 7) // 8)
+    y0 = ops.conv2d_wino_bx3(x, U, b, r, pool2=pool)
+    y1, y1a = ops.conv2d_wino_bx3(x, U, b, r, pool2=pool, act_out=ops.ACT_ELU, want_stats=True)
+    assert torch.equal(y0, y1) and hasattr(y1, "_ipdm_partials") and tuple(y1._ipdm_partials.shape) == (B, Cout, P, 3)
+    assert float(y1._ipdm_partials[..., 0].sum(dim=2).min()) == oh * ow == float(y1._ipdm_partials[..., 0].sum(dim=2).max())
+    alpha, gamma, beta = (torch.randn(Cout, generator=gen).cuda() for _ in range(3))
+    c_part = ops.instnorm_plus_coef(y1, alpha, gamma, beta)
+    c_full = ops.instnorm_plus_coef(y0, alpha, gamma, beta)                 # no partials on y0: reads the tensor
+    assert (c_part - c_full).abs().max() <= 2e-5 * c_full.abs().max()
+    yd = y0.double()
+    mean = yd.mean(dim=(2, 3))
+    rstd = 1.0 / torch.sqrt(yd.var(dim=(2, 3), unbiased=False) + 1e-5)
+    assert (c_part[..., 0].double() - mean).abs().max() <= 1e-6 * mean.abs().max()
+    assert ((c_part[..., 1] / gamma).double() / rstd - 1).abs().max() <= 1e-5
+
+
+def test_wino_bx3_statistics_epilogue_unsupported(ops):
+    from inverseproblemwithdiffusionmodel_amd import _lib
+    lib = _lib.lib
+    assert lib.ipdm_conv2d_wino_bx3_stats_partials(256, 256, 16, 16, 1, 0) == 0        # small-image kernels
+    assert lib.ipdm_conv2d_wino_bx3_stats_partials(256, 256, 32, 32, 2, 0) == 0        # dilated
+    assert lib.ipdm_conv2d_wino_bx3_stats_partials(16, 64, 64, 64, 1, 0) == 0          # one chunk: not the persistent kernel
+    x = torch.randn(1, 256, 16, 16).cuda()
+    U = ops.conv_wino_bx3_weight(torch.randn(512, 256, 3, 3).cuda())
+    y = ops.conv2d_wino_bx3(x, U, want_stats=True)                                     # silently without partials
+    assert not hasattr(y, "_ipdm_partials")
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(3, 1, 128, 32, 32), (2, 2, 20, 12, 16), (2, 3, 128, 16, 32), (1, 1, 5, 1, 4),
                                             (3, 128, 1, 32, 32), (2, 24, 2, 12, 16), (2, 128, 3, 16, 32), (1, 7, 1, 1, 4),
                                             (2, 1, 1, 8, 8), (2, 3, 3, 9, 12), (2, 16, 1, 6, 512), (1, 16, 2, 5, 24)])
