@@ -330,6 +330,14 @@ int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const float* bias, c
  * InstanceNorm++ coefficients of the FOLLOWING normalisation (normalization.py:163-176) without reading the tensor again.
  * ipdm_conv2d_wino_bx3_stats_partials returns P for a layer shape, 0 where the epilogue does not exist (small / dilated
  * images, W % 4 != 0): callers then use ipdm_instnorm_plus_coef_f32 on the tensor as before. */
+/* Split-K form of the Winograd launch for 16-pixel layers with fewer than 512 output channels, whose (image, channel tile)
+ * pairs alone leave most of the chip idle: ipdm_conv2d_wino_bx3_splitk returns the number of K parts for a layer shape (1: use
+ * the plain call; a function of the shape only, never of the batch); with ksplit > 1 the parts write raw partial results to
+ * `work` (ksplit * B * Cout * H * W floats) and a second pass adds them in fixed order with bias / residual / activation. */
+int ipdm_conv2d_wino_bx3_splitk(int Cin, int Cout, int H, int W, int dilation);
+int ipdm_conv2d_wino_bx3_splitk_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
+                                    float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
+                                    int ksplit, float* work, void* stream);
 int ipdm_conv2d_wino_bx3_stats_partials(int Cin, int Cout, int H, int W, int dilation, int pool2);
 int ipdm_conv2d_wino_bx3_stats_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
                                    float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,

@@ -78,6 +78,8 @@ SIGNATURES = {
     "ipdm_conv2d_wino_bx3_supported": [c_int, c_int, c_int, c_int, c_int],
     "ipdm_conv2d_wino_bx3_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "ipdm_conv2d_wino_bx3_stats_partials": [c_int, c_int, c_int, c_int, c_int, c_int],
+    "ipdm_conv2d_wino_bx3_splitk": [c_int, c_int, c_int, c_int, c_int],
+    "ipdm_conv2d_wino_bx3_splitk_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "ipdm_conv2d_wino_bx3_stats_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "ipdm_instnorm_plus_coef_partials_f32": [P, c_int, P, P, P, P, c_int, c_int, P],
     "ipdm_zero_insert2_f32": [P, P, c_int, c_int, c_int, P],

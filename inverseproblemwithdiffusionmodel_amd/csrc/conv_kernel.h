@@ -59,6 +59,13 @@ struct ConvArgs {
                              //   InstanceNorm++ needs, so that it does not read the tensor again
 };
 
+// split-K second pass (conv_bx3.hip): out = bias + sum_s partial[s] (fixed order) + residual; out_act = act_out(out)
+__global__ __launch_bounds__(256) void bx3_splitk_reduce_kernel(const float* __restrict__ partial, int ksplit,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ residual, float* out,
+                                                                float* out_act, int act_out, int Cout, int64_t plane,
+                                                                int64_t total);
+
 // NCT x NPT MFMA tiles per wave, WCO x WPX waves (WCO*WPX == 4), PW = pixel-tile width (16 or 32),
 // DMAX = largest dilation the LDS patch is sized for, KC = input channels per chunk, KS = 1 or 3.
 template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KC, int KS>

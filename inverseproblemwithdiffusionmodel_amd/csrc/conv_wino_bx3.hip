@@ -467,7 +467,11 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 
 // STATS: the epilogue also reduces every (channel, tile group) of the workgroup's tile block to (count, mean, sum of squared
 // deviations) of the stored result and writes them to a.stats (own instantiation, same reason as POOL).
-template <int TX, int TY, bool CO_MAJOR, bool DMA4, bool POOL = false, bool STATS = false>
+// KSP: the K loop of a tile is dealt to a.ksplit workgroups (each a contiguous range of n_cc / ksplit chunks); every part
+// writes its raw A^T M A to its own plane set of a.out (= the caller's partial-sum workspace [ksplit][B][Cout][H][W]) and
+// bx3_splitk_reduce_kernel adds the parts in fixed order with bias / residual / activation.  For 16-pixel layers whose
+// (image, channel tile) pairs alone leave most of the chip idle.
+template <int TX, int TY, bool CO_MAJOR, bool DMA4, bool POOL = false, bool STATS = false, bool KSP = false>
 __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int total_tiles) {
   constexpr int QC = TX / 2 + 2, RC4 = 4 * QC;               // quads / floats per raw row (x0-4 .. x0+2TX+3)
   constexpr int QN = (2 * TY + 2) * QC;                       // quads per channel
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   const int h = lane >> 5, j = lane & 31;
   const int HW = a.H * a.W;
   const int n_cc = a.Cin / X_KC, n_ct = a.Cout / 32;
-  const int n_chunks = n_cc;                                  // >= 2 (launcher)
+  const int n_chunks = KSP ? n_cc / a.ksplit : n_cc;           // >= 2 (launcher)
   const int p0 = 2 * wave;
 
   // ---- this workgroup's tile list: first, stride, end (linear tile order, channel tile fastest) ----
@@ -497,10 +501,18 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   int tile = x_start + slot;
   if (tile >= x_end) return;                                  // uniform: whole workgroup
 
-  struct Geo { int b, y0, x0, co_tile; };
+  struct Geo { int b, y0, x0, co_tile, c0, ks; };               // c0: first chunk of this workgroup's K range (KSP)
   auto geo_of = [&](int L) {
     Geo g;
-    const int n_px = total_tiles / a.co_tiles;
+    g.ks = 0;
+    g.c0 = 0;
+    int n_px = total_tiles / a.co_tiles;
+    if constexpr (KSP) {                                        // K part fastest: the parts of a tile share its input in L2
+      g.ks = L % a.ksplit;
+      L /= a.ksplit;
+      n_px /= a.ksplit;
+      g.c0 = g.ks * n_chunks;
+    }
     g.co_tile = CO_MAJOR ? L / n_px : L % a.co_tiles;
     int t = CO_MAJOR ? L % n_px : L / a.co_tiles;
     const int tx = t % a.tiles_x;
@@ -520,12 +532,14 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   // chunk's 16 channels are one packed image of NI x 64 quads, wave w issues pieces w, w+8, w+16, w+24
   int dma_off[DMA4 ? 4 : 6];
   int dma_b = 0;                                              // image index the offsets belong to
+  [[maybe_unused]] int dma_c0 = 0;                            // ... and the first chunk of its K range
   // every wave issues exactly four pieces per chunk (a wave without a k-th piece repeats its previous one: same bytes to
   // the same place), so that the number of DMA instructions in flight is a compile-time constant: with a wave-uniform
   // branch around them hipcc cannot count, and waits for vmcnt(0) -- i.e. for the DMA -- at the next fragment use
   auto dma_piece = [&](int k) { return wave + 8 * k < NI ? wave + 8 * k : wave + 8 * (k - 1); };
   auto set_dma_geo = [&](const Geo& g) {
     dma_b = g.b;
+    if constexpr (KSP) dma_c0 = g.c0;
     if constexpr (DMA4) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -548,6 +562,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     }
   };
   auto issue_dma = [&](int chunk) {
+    if constexpr (KSP) chunk += dma_c0;
     if constexpr (DMA4) {
       const int soff = (int)(((size_t)dma_b * a.Cin + chunk * X_KC) * HW * 4);
 #pragma unroll
@@ -650,7 +665,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   // ---- prologue of the first tile ----
   Geo cur_g = geo_of(tile);
   bf16x8 afr[2][2][3];
-  load_A(afr[0], p0, 0, cur_g.co_tile);
+  load_A(afr[0], p0, cur_g.c0, cur_g.co_tile);
   set_dma_geo(cur_g);
   issue_dma(0);
   __builtin_amdgcn_s_waitcnt(0);
@@ -688,7 +703,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       const int dma_chunk = dma_next ? ch + 2 - n_chunks : ch + 2;
       if (ch + 2 == n_chunks) set_dma_geo(next_g);            // from here on the raw stage belongs to the next tile
       const bool a_next = ch + 1 >= n_chunks;
-      const int a_chunk = a_next ? 0 : ch + 1;
+      const int a_chunk = a_next ? next_g.c0 : cur_g.c0 + ch + 1;
       const int a_cot = a_next ? next_g.co_tile : cur_g.co_tile;
       bf16x8 bs[2][3];
       float raw[8];
@@ -704,7 +719,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
           store_patch(nxt, 2 * wave);
           read_patch(2 * wave + 1);
           store_patch(nxt, 2 * wave + 1);
-          load_A(afr[1], p0 + 1, ch, cur_g.co_tile);
+          load_A(afr[1], p0 + 1, cur_g.c0 + ch, cur_g.co_tile);
         }
         if constexpr (st == 1) issue_dma(dma_chunk);
         if constexpr (st == 2) load_A(afr[0], p0, a_chunk, a_cot);
@@ -763,7 +778,8 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       const int oy = cur_g.y0 + 2 * (T / TX), ox = cur_g.x0 + 2 * (T % TX);
       const int co = co0 + c * 32 + ecg * 2 + i;
       if constexpr (POOL) return (((size_t)cur_g.b * a.Cout + co) * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1);
-      return ((size_t)cur_g.b * a.Cout + co) * HW + (size_t)(oy + ii) * a.W + ox;
+      const size_t part = KSP ? (size_t)cur_g.ks * a.B * a.Cout * HW : 0;      // this K part's plane set of the workspace
+      return part + ((size_t)cur_g.b * a.Cout + co) * HW + (size_t)(oy + ii) * a.W + ox;
     };
     auto in_range = [&](int tg) {
       const int T = tg * 32 + etile;
@@ -1406,6 +1422,51 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
   return ipdm_launch_status();
 }
 
+// K parts that pay for a layer shape (a function of the SHAPE only, so that a sample's bits do not depend on its batch):
+// undilated images of at most 16 x 16 pixels with fewer than 512 output channels -- (image, channel tile) pairs alone fill
+// under half of the chip at the production batch -- run as two K halves when each half keeps at least two chunks
+int wino_bx3_ksplit_for(int Cin, int Cout, int H, int W, int dilation) {
+  static int enabled = -1;                       // IPDM_WBX3_KSPLIT=0: off (tuning / fallback)
+  if (enabled < 0) {
+    const char* e = getenv("IPDM_WBX3_KSPLIT");
+    enabled = e ? atoi(e) : 1;
+  }
+  if (!enabled || !wino_persist()) return 1;
+  if (dilation != 1 || W > 16 || H > 16 || W % 4 || H % 2 || Cout % X_CO || Cout >= 512) return 1;
+  if (Cin % (2 * X_KC) || Cin / X_KC < 4) return 1;
+  return 2;
+}
+
+int conv_wino_bx3_launch_ksplit(ConvArgs a, int ksplit, float* work, hipStream_t s) {
+  if (ksplit != wino_bx3_ksplit_for(a.Cin, a.Cout, a.H, a.W, a.dil) || ksplit < 2 || !work) return IPDM_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a.x) & 15) != 0) return IPDM_EUNSUPPORTED;          // 16-byte LDS-DMA form only
+  const float* bias = a.bias;
+  const float* residual = a.residual;
+  float* out = a.out;
+  float* out_act = a.out_act;
+  a.tiles_x = (a.W + 15) / 16;
+  a.tiles_y = (a.H + 15) / 16;
+  a.co_tiles = a.Cout / X_CO;
+  a.ksplit = ksplit;
+  a.bias = nullptr; a.residual = nullptr; a.out_act = nullptr; a.out = work; a.pool2 = 0; a.stats = nullptr;
+  const int64_t nblk = (int64_t)a.B * a.tiles_x * a.tiles_y * a.co_tiles * ksplit;
+  if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, true, false, false, true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
+    attr_set = true;
+  }
+  const int per_xcd = (int)((nblk + 7) / 8);
+  const int S = per_xcd < cus_per_xcd() ? per_xcd : cus_per_xcd();
+  hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<8, 8, true, true, false, false, true>), dim3((unsigned)(8 * S)), dim3(512),
+                     X_LDS_BYTES, s, a, (int)nblk);
+  const int64_t plane = (int64_t)a.H * a.W, total = (int64_t)a.B * a.Cout * plane;
+  hipLaunchKernelGGL(bx3_splitk_reduce_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, s, work, ksplit, bias, residual,
+                     out, out_act, a.act_out, a.Cout, plane, total);
+  return ipdm_launch_status();
+}
+
 int conv_wino_bx3_weights(const float* w, void* U, int Cout, int Cin, hipStream_t s) {
   const int n_cc = (Cin + 15) / 16, n_ct = (Cout + 31) / 32;
   const int64_t total = (int64_t)16 * n_cc * n_ct * 512;
@@ -1455,6 +1516,30 @@ extern "C" int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const flo
                                         float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H, int W,
                                         int dilation, int pool2, void* stream) {
   return wino_bx3_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, pool2, nullptr, stream);
+}
+
+/* Split-K form for 16-pixel layers with fewer than 512 output channels: ipdm_conv2d_wino_bx3_splitk returns the number of K
+ * parts (1: use the plain call; a function of the layer shape only), the _f32 call runs the parts into `work`
+ * (ksplit * B * Cout * H * W floats) and adds them in fixed order with bias / residual / activation. */
+extern "C" int ipdm_conv2d_wino_bx3_splitk(int Cin, int Cout, int H, int W, int dilation) {
+  ConvArgs a;
+  a.coef = nullptr; a.act = IPDM_ACT_NONE; a.dil = dilation; a.D = 1; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.B = 1;
+  if (!wino_bx3_ok(a, 3)) return 1;
+  return wino_bx3_ksplit_for(Cin, Cout, H, W, dilation);
+}
+
+extern "C" int ipdm_conv2d_wino_bx3_splitk_f32(const float* x, const void* U, const float* bias, const float* residual,
+                                               float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H,
+                                               int W, int dilation, int ksplit, float* work, void* stream) {
+  IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && dilation >= 1 && ksplit >= 2);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && U && work && (out || out_act) && x != out && x != out_act);
+  ConvArgs a;
+  a.x = x; a.wt = (const float*)U; a.bias = bias; a.coef = nullptr; a.residual = residual; a.out = out; a.out_act = out_act;
+  a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = dilation; a.act = IPDM_ACT_NONE;
+  a.D = 1; a.kd = 1; a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = nullptr;
+  if (!wino_bx3_ok(a, 3)) return IPDM_EUNSUPPORTED;
+  return conv_wino_bx3_launch_ksplit(a, ksplit, work, ipdm_stream(stream));
 }
 
 // partials per plane the statistics epilogue writes for this layer shape (0: that epilogue does not serve it)

@@ -837,6 +837,20 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     nb = wino_bx3_max_batch(Cin, H, W, dilation)
+    ksplit = 1 if pool2 or x.data_ptr() % 16 else wino_bx3_splitk(Cin, Cout, H, W, dilation)
+    if ksplit > 1:                       # 16-pixel layers with few channel tiles: two K halves + a fixed-order reduction
+        for b0 in range(0, B, nb):
+            b1 = min(B, b0 + nb)
+            work = torch.empty((ksplit, b1 - b0, Cout, H, W), dtype=torch.float32, device=x.device)
+            call("ipdm_conv2d_wino_bx3_splitk_f32", _ptr(x[b0:b1]), _ptr(U.blob), _ptr(bias),
+                 _ptr(None if residual is None else residual[b0:b1]), _ptr(None if out is None else out[b0:b1]),
+                 _ptr(None if out_act is None else out_act[b0:b1]), act_out, b1 - b0, Cin, Cout, H, W, dilation, ksplit,
+                 _ptr(work), _stream())
+        if CONV_TRACE is not None:
+            e1.record()
+            CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, res=residual is not None,
+                                   n_out=int(raw) + int(want_act), pool2=False, ksplit=ksplit, e0=e0, e1=e1))
+        return (out, out_act) if want_act else out
     part = None
     if want_stats and raw and USE_STATS_EPILOGUE and x.data_ptr() % 16 == 0:
         P = int(_lib.lib.ipdm_conv2d_wino_bx3_stats_partials(Cin, Cout, H, W, dilation, int(bool(pool2))))
@@ -869,9 +883,16 @@ def wino_bx3_pays(Cin, Cout, H, W, dilation=1, B=None):
     The rule depends on the LAYER SHAPE ONLY -- never on the batch -- so that a sample's bits do not depend on how many
     other samples share its GPU (sharding.py's invariance; `B` is accepted and ignored for old call sites)."""
     if W <= 16 and dilation == 1:
+        if wino_bx3_splitk(Cin, Cout, H, W, dilation) > 1:      # ... unless the layer runs as two K halves (shape rule too)
+            return True
         if H > 16 or Cout < 512 or Cin < 32:
             return False
     return conv_wino_bx3_supported(Cin, Cout, H, W, dilation)
+
+
+def wino_bx3_splitk(Cin, Cout, H, W, dilation=1):
+    """K parts of the Winograd launch for this layer shape (1 = plain launch); never a function of the batch"""
+    return int(_lib.lib.ipdm_conv2d_wino_bx3_splitk(int(Cin), int(Cout), int(H), int(W), int(dilation)))
 
 
 def wino_bx3_max_batch(Cin, H, W, dilation=1):

@@ -218,11 +218,15 @@ def test_conv_dispatch_host_rules():
     assert L.ipdm_conv2d_wino_bx3_supported(512, 512, 16, 16, 4) == 1 and L.ipdm_conv2d_wino_bx3_supported(512, 512, 18, 16, 4) == 0
     assert L.ipdm_conv2d_wino_bx3_supported(64, 64, 31, 32, 1) == 0
     # dispatch rule of the modules: a function of the LAYER SHAPE only (a batch-dependent rule makes a
-    # sample's bits depend on how many samples share its GPU); 16-pixel undilated images only from 512 output channels
-    assert ops.wino_bx3_pays(512, 512, 16, 16, 1) and not ops.wino_bx3_pays(256, 256, 16, 16, 1)
+    # sample's bits depend on how many samples share its GPU); 16-pixel undilated images: plain Winograd launch from 512
+    # output channels, two K halves below that (where each half keeps >= 2 chunks), else the direct kernel
+    assert ops.wino_bx3_pays(512, 512, 16, 16, 1) and ops.wino_bx3_pays(256, 256, 16, 16, 1)
+    assert ops.wino_bx3_splitk(512, 512, 16, 16) == 1 and ops.wino_bx3_splitk(256, 256, 16, 16) == 2
+    assert not ops.wino_bx3_pays(32, 64, 16, 16, 1) and ops.wino_bx3_splitk(32, 64, 16, 16) == 1
     assert ops.wino_bx3_pays(128, 128, 128, 128, 1) and ops.wino_bx3_pays(512, 512, 16, 16, 2)
     for B in (1, 2, 13, 14, 28, 210):
-        assert ops.wino_bx3_pays(512, 512, 16, 16, 1, B=B) and not ops.wino_bx3_pays(256, 256, 16, 16, 1, B=B)
+        assert ops.wino_bx3_pays(512, 512, 16, 16, 1, B=B) and ops.wino_bx3_pays(256, 256, 16, 16, 1, B=B)
+        assert not ops.wino_bx3_pays(32, 64, 16, 16, 1, B=B)
     # batches beyond the kernel's 32-bit buffer offsets run as several launches of the SAME kernel
     assert ops.wino_bx3_pays(384, 128, 256, 256, 1) and ops.wino_bx3_max_batch(384, 256, 256) == 10
     assert ops.wino_bx3_max_batch(128, 128, 128) == 127 and ops.wino_bx3_max_batch(512, 16, 16, 4) == 1023

@@ -584,6 +584,40 @@ def test_wino_bx3_statistics_epilogue(ops, B, Cin, Cout, H, W, pool, res):
     assert ((c_part[..., 1] / gamma).double() / rstd - 1).abs().max() <= 1e-5
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,res,act", [(3, 256, 256, 16, 16, True, True), (1, 64, 64, 16, 16, False, False),
+                                                     (2, 512, 256, 16, 16, True, False), (2, 128, 128, 8, 16, False, True),
+                                                     (5, 256, 128, 16, 12, True, True)])
+def test_wino_bx3_split_k(ops, B, Cin, Cout, H, W, res, act):
+    """16-pixel layers with fewer than 512 output channels run as two K halves of the persistent Winograd kernel plus the
+    fixed-order reduction: against a float64 convolution, and bit-identical whatever the batch around a sample"""
+    gen = torch.Generator().manual_seed(43)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.05
+    b = torch.randn(Cout, generator=gen)
+    r = torch.randn(B, Cout, H, W, generator=gen) if res else None
+    assert ops.wino_bx3_splitk(Cin, Cout, H, W) == 2 and ops.wino_bx3_pays(Cin, Cout, H, W)
+    U = ops.conv_wino_bx3_weight(w.cuda())
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if res:
+        want = want + r.double()
+    got = ops.conv2d_wino_bx3(x.cuda(), U, b.cuda(), None if r is None else r.cuda(),
+                              act_out=ops.ACT_ELU if act else ops.ACT_NONE)
+    if act:
+        got, got_act = got
+        assert (got_act.cpu().double() - F.elu(want)).abs().max() <= 4e-6 * want.abs().max()
+    assert (got.cpu().double() - want).abs().max() <= 4e-6 * want.abs().max()
+    one = ops.conv2d_wino_bx3(x[B - 1:].cuda(), U, b.cuda(), None if r is None else r[B - 1:].cuda())
+    assert torch.equal(one.cpu(), got.cpu()[B - 1:])
+
+
+def test_wino_bx3_split_k_rule_is_shape_only(ops):
+    assert ops.wino_bx3_splitk(256, 512, 16, 16) == 1          # enough channel tiles: plain launch
+    assert ops.wino_bx3_splitk(256, 256, 32, 32) == 1          # wide image
+    assert ops.wino_bx3_splitk(256, 256, 16, 16, 2) == 1       # dilated
+    assert ops.wino_bx3_splitk(32, 64, 16, 16) == 1            # a K half would be a single chunk
+    assert ops.wino_bx3_splitk(256, 256, 16, 16) == 2
+
+
 def test_wino_bx3_statistics_epilogue_unsupported(ops):
     from inverseproblemwithdiffusionmodel_amd import _lib
     lib = _lib.lib
