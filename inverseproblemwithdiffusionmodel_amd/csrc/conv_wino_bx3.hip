@@ -471,10 +471,19 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // writes its raw A^T M A to its own plane set of a.out (= the caller's partial-sum workspace [ksplit][B][Cout][H][W]) and
 // bx3_splitk_reduce_kernel adds the parts in fixed order with bias / residual / activation.  For 16-pixel layers whose
 // (image, channel tile) pairs alone leave most of the chip idle.
-template <int TX, int TY, bool CO_MAJOR, bool DMA4, bool POOL = false, bool STATS = false, bool KSP = false>
+// POLY (16 x 16 images, any dilation d): the workgroup's 64 tiles are the image's d*d polyphase sub-images (a dilation-d
+// convolution is d*d undilated ones on the d-subsampled images; tile t = ((sy*d + sx)*THS + tyy)*TWS + txx covers outputs
+// (d*(2 tyy + i) + sy, d*(2 txx + j) + sx)).  The raw stage holds the WHOLE image of a chunk's 16 channels, padded: 17 rows
+// (the last one all zero: where out-of-image patch rows point) of 24 floats (four zero columns on either side), filled by
+// 26 16-byte LDS-DMA pieces per chunk whose out-of-image quads the range check zeroes; a thread gathers its 4 x 4 patch
+// from there (16 LDS reads) instead of 16 scattered 4-byte global loads per patch -- the address path was what held the
+// register-staged kernel at 12.7 k cycles per chunk on dilation-2 layers.
+template <int TX, int TY, bool CO_MAJOR, bool DMA4, bool POOL = false, bool STATS = false, bool KSP = false, bool POLY = false>
 __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int total_tiles) {
-  constexpr int QC = TX / 2 + 2, RC4 = 4 * QC;               // quads / floats per raw row (x0-4 .. x0+2TX+3)
-  constexpr int QN = (2 * TY + 2) * QC;                       // quads per channel
+  static_assert(!POLY || (TX == 8 && TY == 8 && DMA4 && !POOL && !STATS && !KSP), "POLY: the 8 x 8 form, plain epilogue");
+  constexpr int PPW = 24, PPH = 17;                           // POLY: padded row pitch / rows per channel
+  constexpr int QC = POLY ? PPW / 4 : TX / 2 + 2, RC4 = 4 * QC;   // quads / floats per raw row (x0-4 .. x0+2TX+3)
+  constexpr int QN = POLY ? PPH * QC : (2 * TY + 2) * QC;     // quads per channel
   constexpr int NI = (X_KC * QN + 63) / 64;                   // wave-instructions per chunk
   static_assert(NI >= 24 && NI <= 32 && NI * 256 <= X_R_ELEMS, "quad image fits the raw stage; pieces 0..23 exist");
   static_assert(TX * TY == X_TILES, "64 tiles per workgroup");
@@ -546,7 +555,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
         const int e = dma_piece(k) * 64 + lane;
         const int cin = e / QN, qq = e - cin * QN;
         const int rr = qq / QC, qc = qq - rr * QC;
-        const int gy = g.y0 - 1 + rr, gx0 = g.x0 - 4 + 4 * qc;
+        const int gy = POLY ? (rr < 16 ? rr : -1) : g.y0 - 1 + rr, gx0 = g.x0 - 4 + 4 * qc;
         const bool ok = e < X_KC * QN && gy >= 0 && gy < a.H && gx0 >= 0 && gx0 < a.W;
         dma_off[k] = ok ? (cin * HW + gy * a.W + gx0) * 4 : 0x40000000;
       }
@@ -585,9 +594,37 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     }
   };
   float dreg[16];
+  // POLY: this thread's tile in the polyphase tile space, and the padded-image offsets of its patch rows / columns
+  const int pd = POLY ? a.dil : 1;
+  auto tile_origin = [&](int tl, int& py, int& px) {
+    const int tws = a.W / (2 * pd), ths = a.H / (2 * pd);
+    const int txx = tl % tws;
+    int r = tl / tws;
+    const int tyy = r % ths;
+    r /= ths;
+    py = pd * (2 * tyy) + r / pd;
+    px = pd * (2 * txx) + r % pd;
+  };
+  [[maybe_unused]] int prow[4], pcol[4];
+  if constexpr (POLY) {
+    int py, px;
+    tile_origin(mytile, py, px);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int gy = py + pd * (e - 1), gx = px + pd * (e - 1);
+      prow[e] = (gy >= 0 && gy < a.H ? gy : 16) * PPW;        // row 16: zeros
+      pcol[e] = gx >= 0 && gx < a.W ? gx + 4 : 0;             // column 0: zero
+    }
+  }
   const int r_lane = DMA4 ? (2 * (mytile / TX)) * RC4 + 2 * (mytile % TX) + 2 : (2 * (mytile / TX)) * RC + 2 * (mytile % TX);
   auto read_patch = [&](int kc) {
-    if constexpr (DMA4) {
+    if constexpr (POLY) {
+      const float* rp = rs + kc * (QN * 4);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) dreg[rr * 4 + cc] = rp[prow[rr] + pcol[cc]];
+    } else if constexpr (DMA4) {
       // patch columns 2txl+3 .. 2txl+6 of the 4-aligned rows.  A lane reads only its own aligned pair (2txl+4, 2txl+5);
       // column 2txl+3 is the left neighbour tile's second element and 2txl+6 the right neighbour's first (lanes of a
       // 16-lane DPP row are consecutive tiles of a tile row), the two tiles at the ends of a tile row read theirs:
@@ -774,6 +811,11 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     float2 resv[AHEAD ? 2 : 1][2][NR];
     float biasv[AHEAD ? 2 : 1][2];
     auto out_index = [&](int c, int tg, int i, int ii) -> size_t {
+      if constexpr (POLY) {                                     // -> the first of the row's two outputs; the second: + d
+        int py, px;
+        tile_origin(tg * 32 + etile, py, px);
+        return ((size_t)cur_g.b * a.Cout + co0 + c * 32 + ecg * 2 + i) * HW + (size_t)(py + pd * ii) * a.W + px;
+      }
       const int T = tg * 32 + etile;
       const int oy = cur_g.y0 + 2 * (T / TX), ox = cur_g.x0 + 2 * (T % TX);
       const int co = co0 + c * 32 + ecg * 2 + i;
@@ -782,6 +824,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       return part + ((size_t)cur_g.b * a.Cout + co) * HW + (size_t)(oy + ii) * a.W + ox;
     };
     auto in_range = [&](int tg) {
+      if constexpr (POLY) return true;                          // exactly 64 tiles per image
       const int T = tg * 32 + etile;
       return cur_g.y0 + 2 * (T / TX) < a.H && cur_g.x0 + 2 * (T % TX) < a.W;
     };
@@ -801,6 +844,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
         for (int ii = 0; ii < NR; ++ii) {
           const size_t o = res_ok ? out_index(c, tg, i, ii) : 0;
           if constexpr (POOL) resv[bf][i][ii] = make_float2(res_p[o], 0.f);
+          else if constexpr (POLY) resv[bf][i][ii] = make_float2(res_p[o], res_p[o + (res_ok ? pd : 0)]);
           else resv[bf][i][ii] = *reinterpret_cast<const float2*>(res_p + o);
         }
       }
@@ -866,11 +910,23 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
               sv[i][2 * ii] = y0v;
               sv[i][2 * ii + 1] = y1v;
             }
-            if (a.out) *reinterpret_cast<float2*>(a.out + o) = make_float2(y0v, y1v);
+            if constexpr (POLY) {
+              if (a.out) {
+                a.out[o] = y0v;
+                a.out[o + pd] = y1v;
+              }
+            } else {
+              if (a.out) *reinterpret_cast<float2*>(a.out + o) = make_float2(y0v, y1v);
+            }
             if (a.out_act) {
               const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
               const float e1 = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
-              *reinterpret_cast<float2*>(a.out_act + o) = make_float2(e0, e1);
+              if constexpr (POLY) {
+                a.out_act[o] = e0;
+                a.out_act[o + pd] = e1;
+              } else {
+                *reinterpret_cast<float2*>(a.out_act + o) = make_float2(e0, e1);
+              }
             }
           }
           }
@@ -1309,7 +1365,35 @@ bool wino_bx3_ok(const ConvArgs& a, int ks) {
   return a.H % 2 == 0 && a.W % 2 == 0 && a.H >= 8;
 }
 
+// dilated 16 x 16 images (the deepest stages of the score networks): the persistent kernel on the polyphase tile space with the
+// whole padded image in the raw stage (a function of the layer shape; IPDM_WBX3_POLY=0: the register-staged kernel)
+bool x_poly(const ConvArgs& a) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("IPDM_WBX3_POLY");
+    enabled = e ? atoi(e) : 1;
+  }
+  return enabled && wino_persist() && a.dil > 1 && a.H == 16 && a.W == 16 && 16 % (2 * a.dil) == 0 && a.Cin >= 2 * X_KC &&
+         !a.pool2 && !a.stats && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
+}
+
 int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
+  if (x_poly(a)) {
+    a.tiles_x = a.tiles_y = 1;
+    a.co_tiles = a.Cout / X_CO;
+    const int64_t nblk = (int64_t)a.B * a.co_tiles;
+    static bool poly_attr = false;
+    if (!poly_attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, true, false, false, false, true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
+      poly_attr = true;
+    }
+    const int per_xcd = (int)((nblk + 7) / 8);
+    const int S = per_xcd < cus_per_xcd() ? per_xcd : cus_per_xcd();
+    hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<8, 8, true, true, false, false, false, true>), dim3((unsigned)(8 * S)),
+                       dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+    return ipdm_launch_status();
+  }
   const bool small = x_small(a);
   const bool small_dma = small && wino_persist() && x_small_dma(a);
   // the pooled epilogue lives in the persistent wide kernels only (the ConvMeanPool layers of the score nets are 32..128

@@ -610,6 +610,29 @@ def test_wino_bx3_split_k(ops, B, Cin, Cout, H, W, res, act):
     assert torch.equal(one.cpu(), got.cpu()[B - 1:])
 
 
+@pytest.mark.parametrize("B,Cin,Cout,dil,res", [(3, 64, 64, 2, True), (2, 256, 512, 2, False), (1, 32, 128, 4, True),
+                                                 (5, 128, 64, 4, False)])
+def test_wino_bx3_dilated_16px_polyphase(ops, B, Cin, Cout, dil, res, monkeypatch):
+    """dilated 16 x 16 layers: the persistent kernel on the polyphase tile space (whole padded image in LDS) against a float64
+    convolution, bit-identical to the register-staged kernel it replaces and independent of the batch around a sample"""
+    import subprocess, sys, os
+    gen = torch.Generator().manual_seed(47)
+    x = torch.randn(B, Cin, 16, 16, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.05
+    b = torch.randn(Cout, generator=gen)
+    r = torch.randn(B, Cout, 16, 16, generator=gen) if res else None
+    U = ops.conv_wino_bx3_weight(w.cuda())
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=dil, dilation=dil)
+    if res:
+        want = want + r.double()
+    got, got_act = ops.conv2d_wino_bx3(x.cuda(), U, b.cuda(), None if r is None else r.cuda(), act_out=ops.ACT_ELU,
+                                       dilation=dil)
+    assert (got.cpu().double() - want).abs().max() <= 4e-6 * want.abs().max()
+    assert (got_act.cpu().double() - F.elu(want)).abs().max() <= 4e-6 * want.abs().max()
+    one = ops.conv2d_wino_bx3(x[B - 1:].cuda(), U, b.cuda(), None if r is None else r[B - 1:].cuda(), dilation=dil)
+    assert torch.equal(one.cpu(), got.cpu()[B - 1:])
+
+
 def test_wino_bx3_split_k_rule_is_shape_only(ops):
     assert ops.wino_bx3_splitk(256, 512, 16, 16) == 1          # enough channel tiles: plain launch
     assert ops.wino_bx3_splitk(256, 256, 32, 32) == 1          # wide image
