@@ -612,10 +612,9 @@ def test_wino_bx3_split_k(ops, B, Cin, Cout, H, W, res, act):
 
 @pytest.mark.parametrize("B,Cin,Cout,dil,res", [(3, 64, 64, 2, True), (2, 256, 512, 2, False), (1, 32, 128, 4, True),
                                                  (5, 128, 64, 4, False)])
-def test_wino_bx3_dilated_16px_polyphase(ops, B, Cin, Cout, dil, res, monkeypatch):
+def test_wino_bx3_dilated_16px_polyphase(ops, B, Cin, Cout, dil, res):
     """dilated 16 x 16 layers: the persistent kernel on the polyphase tile space (whole padded image in LDS) against a float64
-    convolution, bit-identical to the register-staged kernel it replaces and independent of the batch around a sample"""
-    import subprocess, sys, os
+    convolution, and independent of the batch around a sample"""
     gen = torch.Generator().manual_seed(47)
     x = torch.randn(B, Cin, 16, 16, generator=gen)
     w = torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.05
