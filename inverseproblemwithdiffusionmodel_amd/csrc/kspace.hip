@@ -262,6 +262,122 @@ __global__ __launch_bounds__(FFT_THREADS) void ald_sense_step_kernel(
   }
 }
 
+// The same iteration tail with the coils in parallel: a rank's batch is 13-14 samples, i.e. 14 of 256 CUs busy for four
+// dependent (FFT, inverse FFT) pairs in the one-workgroup-per-sample kernel above.  Here workgroup (coil, b) forms the
+// Langevin update z in registers (every coil workgroup of a sample computes the same z: the noise is injected or a pure
+// function of (seed, sample, step, element)), does ITS coil's transform pair and writes r_c = conj-free S_c F^-1[M (F S_c z - y_c)]
+// to work[b][coil]; ald_sense_combine_kernel then forms z once more and x = z - coef * (((r_0 + r_1) + r_2) + ...) in the
+// sequential kernel's order: bit-identical results, 56 workgroups instead of 14, one transform pair deep instead of four.
+__device__ __forceinline__ void langevin_value(const float* xr, const float* xi, const float* __restrict__ g_re,
+                                               const float* __restrict__ g_im, const float* __restrict__ n_re,
+                                               const float* __restrict__ n_im, float step, float noise_scale, uint64_t seed,
+                                               int64_t sample_offset, int64_t step_id, int b, int HW, int e, float& zr,
+                                               float& zi) {
+  const size_t gi = (size_t)b * HW + e;
+  float nr, ni;
+  if (n_re) {
+    nr = n_re[gi];
+    ni = n_im[gi];
+  } else {
+    float q[4];
+    const int lane4 = e & 3;
+    ipdm_philox_normal4(seed, sample_offset + b, step_id, 0, (uint32_t)(e >> 2), q);
+    nr = lane4 == 0 ? q[0] : lane4 == 1 ? q[1] : lane4 == 2 ? q[2] : q[3];
+    ipdm_philox_normal4(seed, sample_offset + b, step_id, 1, (uint32_t)(e >> 2), q);
+    ni = lane4 == 0 ? q[0] : lane4 == 1 ? q[1] : lane4 == 2 ? q[2] : q[3];
+  }
+  zr = xr[e] + step * g_re[gi] + nr * noise_scale;
+  zi = xi[e] + step * g_im[gi] + ni * noise_scale;
+}
+
+template <bool LANGEVIN>
+__global__ __launch_bounds__(FFT_THREADS) void ald_sense_coil_kernel(
+    const float* x_re, const float* x_im, const float* __restrict__ g_re, const float* __restrict__ g_im,
+    const float* __restrict__ n_re, const float* __restrict__ n_im, float step, float noise_scale, uint64_t seed,
+    int64_t sample_offset, int64_t step_id, const ipdm_sched_t* __restrict__ sched, const float2* __restrict__ y,
+    const float* __restrict__ sens, const uint8_t* __restrict__ mask, int mask_t, float coef, float2* work, int B,
+    int n_coils, int H, int W) {
+  FFT_LDS_SETUP(H, W)
+  if (sched) {
+    step = sched->step;
+    noise_scale = sched->noise_scale;
+    coef = sched->coef;
+    step_id = sched->step_id;
+  }
+  if (coef == 0.f) return;                                    // the combine pass then only applies the Langevin update
+  const int HW = H * W;
+  const int coil = blockIdx.x, b = blockIdx.y;
+  const float scale = rsqrtf((float)HW);
+  const float* xr = x_re + (size_t)b * HW;
+  const float* xi = x_im + (size_t)b * HW;
+  const float* sm = sens + (size_t)coil * HW;
+  for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+    float zr = xr[e], zi = xi[e];
+    if constexpr (LANGEVIN)
+      langevin_value(xr, xi, g_re, g_im, n_re, n_im, step, noise_scale, seed, sample_offset, step_id, b, HW, e, zr, zi);
+    const int r = e / W, c = e - r * W;
+    const float sg = sign_rc(r, c) * sm[e];
+    L.buf[e] = make_float2(zr * sg, zi * sg);
+  }
+  __syncthreads();
+  fft2_lds(L, H, W, false);
+  const float2* yc = y + ((size_t)coil * B + b) * HW;
+  for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+    const int r = e / W, c = e - r * W;
+    const float2 v = L.buf[e];
+    float2 res = make_float2(0.f, 0.f);
+    if (mask_at(mask, mask_t, b, W, c)) {
+      const float sg = sign_rc(r, c);
+      const float2 yy = yc[e];
+      res = make_float2(v.x * scale - sg * yy.x, v.y * scale - sg * yy.y);
+    }
+    L.buf[e] = res;
+  }
+  __syncthreads();
+  fft2_lds(L, H, W, true);
+  float2* wk = work + ((size_t)b * n_coils + coil) * HW;
+  for (int e = threadIdx.x; e < HW; e += FFT_THREADS) {
+    const int r = e / W, c = e - r * W;
+    const float2 v = L.buf[e];
+    const float w = sign_rc(r, c) * scale * sm[e];
+    wk[e] = make_float2(v.x * w, v.y * w);
+  }
+}
+
+template <bool LANGEVIN>
+__global__ __launch_bounds__(256) void ald_sense_combine_kernel(
+    float* x_re, float* x_im, const float* __restrict__ g_re, const float* __restrict__ g_im,
+    const float* __restrict__ n_re, const float* __restrict__ n_im, float step, float noise_scale, uint64_t seed,
+    int64_t sample_offset, int64_t step_id, const ipdm_sched_t* __restrict__ sched, float coef,
+    const float2* __restrict__ work, int B, int n_coils, int HW) {
+  if (sched) {
+    step = sched->step;
+    noise_scale = sched->noise_scale;
+    coef = sched->coef;
+    step_id = sched->step_id;
+  }
+  const int b = blockIdx.y;
+  float* xr = x_re + (size_t)b * HW;
+  float* xi = x_im + (size_t)b * HW;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < HW; e += gridDim.x * 256) {
+    float zr = xr[e], zi = xi[e];
+    if constexpr (LANGEVIN)
+      langevin_value(xr, xi, g_re, g_im, n_re, n_im, step, noise_scale, seed, sample_offset, step_id, b, HW, e, zr, zi);
+    if (coef != 0.f) {
+      const float2* wk = work + (size_t)b * n_coils * HW + e;
+      float2 a = wk[0];
+      for (int c = 1; c < n_coils; ++c) {                     // a_c = r_c + a_(c-1): the one-workgroup kernel's order
+        const float2 rc = wk[(size_t)c * HW];
+        a = make_float2(rc.x + a.x, rc.y + a.y);
+      }
+      zr = zr - coef * a.x;
+      zi = zi - coef * a.y;
+    }
+    xr[e] = zr;
+    xi[e] = zi;
+  }
+}
+
 // Single-coil iteration tail (RandomUndersamplingFourier: A = M F, no coil maps), planar real/imag, in place:
 // Langevin update (optional) + one of the reference's three single-coil data-consistency operators
 //   mode 0  L2Penalty   x = z - coef * F^-1[ M (M F z - y) ]               (proximal_op.py:19-51, coef = 0.05 a/(l K), K = B)
@@ -349,6 +465,27 @@ static int set_lds_limit(K kernel, size_t bytes) {
   return e == hipSuccess ? IPDM_OK : (int)e;
 }
 
+template <bool LANGEVIN>
+static int launch_sense_step_coils(float* x_re, float* x_im, const float* g_re, const float* g_im, const float* n_re,
+                                   const float* n_im, float step, float noise_scale, uint64_t seed, int64_t sample_offset,
+                                   int64_t step_id, const ipdm_sched_t* sched, const float2* y, const float* sens,
+                                   const uint8_t* mask, int mask_t, float coef, float2* work, int B, int n_coils, int H,
+                                   int W, hipStream_t st) {
+  if (B > 65535) return IPDM_EUNSUPPORTED;
+  const size_t lds = lds_bytes(H, W);
+  const int rc = set_lds_limit(ald_sense_coil_kernel<LANGEVIN>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ald_sense_coil_kernel<LANGEVIN>, dim3(n_coils, B), dim3(FFT_THREADS), lds, st, x_re, x_im, g_re, g_im,
+                     n_re, n_im, step, noise_scale, seed, (long long)sample_offset, (long long)step_id, sched, y, sens, mask,
+                     mask_t, coef, work, B, n_coils, H, W);
+  const int HW = H * W;
+  int gx = (HW + 255) / 256;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(ald_sense_combine_kernel<LANGEVIN>, dim3(gx, B), dim3(256), 0, st, x_re, x_im, g_re, g_im, n_re, n_im,
+                     step, noise_scale, seed, (long long)sample_offset, (long long)step_id, sched, coef, work, B, n_coils, HW);
+  return ipdm_launch_status();
+}
+
 }  // namespace
 
 extern "C" int64_t ipdm_fft2c_workspace_bytes(int batch, int H, int W) {
@@ -356,9 +493,19 @@ extern "C" int64_t ipdm_fft2c_workspace_bytes(int batch, int H, int W) {
   return (lds_fft_ok(H, W) || ipdm_kspace_large::large_ok(H, W)) ? 0 : (int64_t)batch * H * W * 8;
 }
 
+// IPDM_SENSE_COILS=0: the one-workgroup-per-sample kernel (tuning / comparison; same bits)
+static int sense_coil_parallel() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("IPDM_SENSE_COILS");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
 extern "C" int64_t ipdm_sense_workspace_bytes(int B, int n_coils, int H, int W) {
   if (B <= 0 || n_coils <= 0 || H <= 0 || W <= 0) return 0;
-  if (lds_fft_ok(H, W)) return (int64_t)B * H * W * 8;        // coil-sum scratch of the single-kernel path
+  if (lds_fft_ok(H, W)) return (int64_t)B * n_coils * H * W * 8;   // one plane per (sample, coil): the coil-parallel path
   return ipdm_kspace_large::workspace_bytes(B, n_coils, H, W);
 }
 
@@ -463,6 +610,10 @@ extern "C" int ipdm_sense_l2prox_f32(const float* z_re, const float* z_im, const
     return ipdm_kspace_large::prox_step(out_re, out_im, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0ull, 0, 0, nullptr,
                                         reinterpret_cast<const float2*>(y), sens, mask, mask_t, coef, 0,
                                         reinterpret_cast<float2*>(work), B, n_coils, H, W, st);
+  if (sense_coil_parallel())
+    return launch_sense_step_coils<false>(out_re, out_im, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0ull, 0, 0, nullptr,
+                                          reinterpret_cast<const float2*>(y), sens, mask, mask_t, coef,
+                                          reinterpret_cast<float2*>(work), B, n_coils, H, W, st);
   size_t lds = lds_bytes(H, W);
   int rc = set_lds_limit(ald_sense_step_kernel<false>, lds);
   if (rc) return rc;
@@ -486,6 +637,10 @@ extern "C" int ipdm_ald_sense_step_f32(float* x_re, float* x_im, const float* g_
                                         step_id, dev_sched, reinterpret_cast<const float2*>(y), sens, mask, mask_t, coef, 0,
                                         reinterpret_cast<float2*>(work), B, n_coils, H, W, ipdm_stream(stream));
   if (!lds_fft_ok(H, W)) return IPDM_EUNSUPPORTED;
+  if (sense_coil_parallel())
+    return launch_sense_step_coils<true>(x_re, x_im, g_re, g_im, noise_re, noise_im, step, noise_scale, seed, sample_offset,
+                                         step_id, dev_sched, reinterpret_cast<const float2*>(y), sens, mask, mask_t, coef,
+                                         reinterpret_cast<float2*>(work), B, n_coils, H, W, ipdm_stream(stream));
   size_t lds = lds_bytes(H, W);
   int rc = set_lds_limit(ald_sense_step_kernel<true>, lds);
   if (rc) return rc;

@@ -382,6 +382,36 @@ def test_inplace_wrappers_reject_bad_operands(ops):
         ops.adam_ascent(x, x.double(), x.clone(), x.clone(), 1e-3, 1)
 
 
+def test_ald_sense_step_coil_parallel_is_bit_identical(ops, tmp_path):
+    """the coil-parallel pair of kernels (one workgroup per (sample, coil) + combine) against the one-workgroup-per-sample
+    kernel (IPDM_SENSE_COILS=0, read once per process -> a child process): same bits, Philox noise included"""
+    import subprocess, sys, os
+    code = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from inverseproblemwithdiffusionmodel_amd import ops
+g = torch.Generator().manual_seed(77)
+B, n, H, W = 3, 4, 128, 128
+x = torch.randn(2, B, H, W, generator=g).cuda(); gr = torch.randn(2, B, H, W, generator=g).cuda()
+y = torch.complex(torch.randn(n, B, H, W, generator=g), torch.randn(n, B, H, W, generator=g)).cuda()
+sens = torch.randn(n, H, W, generator=g).cuda()
+mask = (torch.rand(1, W, generator=g) < 0.3).to(torch.uint8).cuda()
+work = ops.sense_workspace(B, n, H, W, "cuda")
+ops.ald_sense_step(x[0], x[1], gr[0], gr[1], y, sens, mask, work, step=0.3, noise_scale=0.7, coef=0.011, seed=5,
+                   sample_offset=9, step_id=1234)
+torch.save(x.cpu(), sys.argv[2])
+"""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, val in (("coils", "1"), ("serial", "0")):
+        out = str(tmp_path / f"{tag}.pt")
+        r = subprocess.run([sys.executable, "-c", code, repo, out], env=dict(os.environ, IPDM_SENSE_COILS=val),
+                           capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(out))
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
 def test_ald_sense_step_matches_oracle(ops):
     rng = np.random.default_rng(6)
     H = W = 128
@@ -398,7 +428,7 @@ def test_ald_sense_step_matches_oracle(ops):
     z = ((x.real + step * g[0] + n[0] * ns) + 1j * (x.imag + step * g[1] + n[1] * ns)).astype(np.complex64)
     want = kspace.l2_penalty_sense(z, y, alpha, 1.0, maps, mask[None])
     x_re, x_im = dev(x.real), dev(x.imag)
-    work = torch.empty(B * H * W * 2, device="cuda")
+    work = ops.sense_workspace(B, maps.shape[0], H, W, "cuda")
     ops.ald_sense_step(x_re, x_im, dev(g[0]), dev(g[1]), dev(y), dev(maps.astype(np.float32)),
                        dev(mask.astype(np.uint8)), work, step=float(step), noise_scale=float(ns), coef=coef,
                        noise_re=dev(n[0]), noise_im=dev(n[1]))
