@@ -484,7 +484,7 @@ def test_instnorm_plus(ops, golden):
     np.testing.assert_allclose(y, F.elu(torch.from_numpy(g["in_y"])).numpy(), atol=3e-6)
 
 
-@pytest.mark.parametrize("shape", [(2, 128, 128, 128), (3, 512, 16, 16), (1, 7, 9, 5)])
+@pytest.mark.parametrize("shape", [(2, 128, 128, 128), (3, 512, 16, 16), (1, 7, 9, 5), (2, 256, 32, 32), (5, 3, 4, 4), (2, 6, 8, 20)])
 def test_instnorm_plus_sizes(ops, shape):
     gen = torch.Generator().manual_seed(8)
     x = torch.randn(shape, generator=gen) * 3 + 50.0            # large mean: exercises the (x - mu) form
