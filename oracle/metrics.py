@@ -4,8 +4,9 @@ Reference anchors: helpers/metrics.py:55-92.  The reference calls scikit-image, 
 installed in this image: these are restatements of skimage's published algorithms
 (skimage.metrics.normalized_root_mse 'euclidean'; structural_similarity with its defaults: 7x7
 uniform window, K1=0.01, K2=0.03, sample covariance, mean over the valid interior) -- parity for
-this file is UNPINNED (no skimage to generate vectors from); it is only used to compare two
-reconstructions with one and the same metric.
+this file is UNPINNED against skimage itself (none here to generate vectors from); what pins it is
+tests/test_oracle_golden.py::test_ssim_against_an_independent_restatement: the published definition
+evaluated by plain loops over windows (no routine shared with this file) and closed forms, to 1e-12.
 """
 import numpy as np
 from scipy.ndimage import uniform_filter

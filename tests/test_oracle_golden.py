@@ -251,6 +251,37 @@ def test_metrics_definitions():
     assert metrics.nrmse(a, b) == pytest.approx(np.linalg.norm(a - b) / np.linalg.norm(a))
 
 
+def test_ssim_against_an_independent_restatement():
+    """scikit-image is absent here, so the SSIM oracle cannot be pinned to skimage's own output.  What can be
+    pinned: the published definition it restates (Wang et al. 2004 with skimage's documented defaults: 7x7 uniform window,
+    K1 = 0.01, K2 = 0.03, SAMPLE covariance i.e. the N/(N-1) factor, data_range 2 for float images, mean over the interior
+    where the window fits) evaluated by plain loops over windows -- no filter routine shared with the oracle -- and the
+    closed forms of constant and affinely related images."""
+    rng = np.random.default_rng(3)
+    a = rng.random((19, 23)) * 2 - 1
+    b = np.clip(a + 0.2 * rng.standard_normal(a.shape), -1, 1)
+    win, K1, K2, L = 7, 0.01, 0.03, 2.0
+    C1, C2 = (K1 * L) ** 2, (K2 * L) ** 2
+    vals = []
+    for i in range(a.shape[0] - win + 1):
+        for j in range(a.shape[1] - win + 1):
+            wa, wb = a[i:i + win, j:j + win].ravel(), b[i:i + win, j:j + win].ravel()
+            ma, mb = wa.mean(), wb.mean()
+            va, vb = wa.var(ddof=1), wb.var(ddof=1)
+            cab = ((wa - ma) * (wb - mb)).sum() / (wa.size - 1)
+            vals.append((2 * ma * mb + C1) * (2 * cab + C2) / ((ma * ma + mb * mb + C1) * (va + vb + C2)))
+    assert metrics.ssim(a, b) == pytest.approx(float(np.mean(vals)), rel=1e-12)
+    # constants: no variance, S = (2 c d + C1) / (c^2 + d^2 + C1)
+    c, d = 0.3, -0.5
+    assert metrics.ssim(np.full((16, 16), c), np.full((16, 16), d)) == pytest.approx((2 * c * d + C1) / (c * c + d * d + C1))
+    # an anti-correlated image of the same brightness scores negative (structure term); a brightness-shifted copy loses
+    # only through the luminance term
+    pos = 0.2 * a + 0.6
+    assert metrics.ssim(pos, 1.2 - pos) < 0 < metrics.ssim(pos, pos + 0.1) < 1
+    # explicit data_range
+    assert metrics.ssim(a, b, data_range=1.0) != pytest.approx(metrics.ssim(a, b))
+
+
 # ---- G18: MAP baseline (SENSEMAP = MAPOptimizer with Adam(0.5, 0.5)) ---------------------------------------------
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_map_sense_golden(golden, tag):
