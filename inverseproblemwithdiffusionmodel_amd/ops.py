@@ -375,6 +375,8 @@ def instnorm_plus_coef(x, alpha, gamma, beta):
     B, C = x.shape[:2]
     coef = torch.empty((B, C, 3), dtype=torch.float32, device=x.device)
     part = getattr(x, "_ipdm_partials", None)
+    if part is not None:
+        del x._ipdm_partials             # single use: whatever touches the tensor afterwards cannot meet stale statistics
     if part is not None and USE_STATS_EPILOGUE and tuple(part.shape[:2]) == (B, C):
         call("ipdm_instnorm_plus_coef_partials_f32", _ptr(part), int(part.shape[2]), _ptr(alpha), _ptr(gamma), _ptr(beta),
              _ptr(coef), B, C, _stream())

@@ -605,6 +605,7 @@ def test_wino_bx3_statistics_epilogue(ops, B, Cin, Cout, H, W, pool, res):
     assert float(y1._ipdm_partials[..., 0].sum(dim=2).min()) == oh * ow == float(y1._ipdm_partials[..., 0].sum(dim=2).max())
     alpha, gamma, beta = (torch.randn(Cout, generator=gen).cuda() for _ in range(3))
     c_part = ops.instnorm_plus_coef(y1, alpha, gamma, beta)
+    assert not hasattr(y1, "_ipdm_partials")                                # single use
     c_full = ops.instnorm_plus_coef(y0, alpha, gamma, beta)                 # no partials on y0: reads the tensor
     assert (c_part - c_full).abs().max() <= 2e-5 * c_full.abs().max()
     yd = y0.double()
