@@ -865,9 +865,12 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
                 _ptr(None if out_act is None else out_act[b0:b1]), act_out, b1 - b0, Cin, Cout, H, W, dilation,
                 int(bool(pool2)))
         if part is not None:
-            call("ipdm_conv2d_wino_bx3_stats_f32", *args, _ptr(part[b0:b1]), _stream())
-        else:
-            call("ipdm_conv2d_wino_bx3_f32", *args, _stream())
+            try:
+                call("ipdm_conv2d_wino_bx3_stats_f32", *args, _ptr(part[b0:b1]), _stream())
+                continue
+            except _lib.IpdmUnsupported:         # e.g. IPDM_WBX3_DMA4=0: no statistics epilogue on that kernel form
+                part = None
+        call("ipdm_conv2d_wino_bx3_f32", *args, _stream())
     if part is not None:
         out._ipdm_partials = part
     if CONV_TRACE is not None:
