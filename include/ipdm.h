@@ -83,8 +83,8 @@ int64_t ipdm_fft2c_workspace_bytes(int batch, int H, int W);
 int ipdm_sense_forward_c64(const float* x, const float* sens, const uint8_t* mask, int mask_t,
                            float* y, int B, int n_coils, int H, int W, void* stream);
 /* Scratch the SENSE / single-coil operators below need for (B, n_coils, H, W):
- *   power-of-two images up to 128x128 (one kernel, image resident in LDS): B*H*W*8 bytes for the proximal operators'
- *   coil sum, nothing for forward / adjoint / SSOS;
+ *   power-of-two images up to 128x128 (image resident in LDS): n_coils*B*H*W*8 bytes for the proximal operators (one
+ *   plane per (sample, coil): the coils of a sample run in parallel workgroups), nothing for forward / adjoint / SSOS;
  *   larger power-of-two images (e.g. the reference's 256x256 ACDC slices, helpers/load_data.py:274; row / column FFT
  *   passes): n_coils*B*H*W*8 bytes for every operator except ipdm_sense_forward_c64 (single-coil: n_coils = 1). */
 int64_t ipdm_sense_workspace_bytes(int B, int n_coils, int H, int W);
