@@ -914,6 +914,7 @@ def test_conv_bx3_3d(ops, dil, Cin, Cout, D, Hh, Ww):
 @pytest.mark.parametrize("B,Cin,Cout,H,W,res,dil", [
     (2, 64, 64, 32, 32, True, 1), (1, 128, 128, 64, 64, False, 1), (3, 256, 256, 32, 32, True, 1),
     (2, 16, 64, 10, 36, False, 1), (1, 128, 256, 128, 128, False, 1), (2, 32, 64, 40, 70, True, 1),   # ragged edges
+    (2, 32, 64, 40, 36, True, 1), (1, 48, 128, 72, 96, True, 1),                                  # ... on the 16-byte DMA form
     (3, 64, 64, 16, 16, True, 1), (2, 64, 128, 16, 16, True, 2), (2, 128, 64, 16, 16, False, 4),      # small / dilated
     (1, 16, 64, 24, 16, False, 2), (1, 16, 64, 32, 32, True, 2),
     (40, 32, 256, 16, 16, True, 1), (80, 32, 128, 12, 16, False, 1)])        # 16-pixel images, persistent DMA path
