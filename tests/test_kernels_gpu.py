@@ -671,6 +671,27 @@ def test_wino_bx3_split_k_rule_is_shape_only(ops):
     assert ops.wino_bx3_splitk(256, 256, 16, 16) == 2
 
 
+def test_wino_bx3_statistics_epilogue_large_mean(ops):
+    """planes with |mean| >> spread (1000 +- 1): the epilogue's one-pass sums are taken about a shift from the data, so the
+    variance keeps the precision the two-pass kernel has"""
+    gen = torch.Generator().manual_seed(42)
+    B, Cin, Cout, H, W = 2, 32, 64, 40, 36
+    x = torch.randn(B, Cin, H, W, generator=gen).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.05).cuda()
+    r = (torch.randn(B, Cout, H, W, generator=gen) + 1000.0).cuda()
+    U = ops.conv_wino_bx3_weight(w)
+    y = ops.conv2d_wino_bx3(x, U, None, r, want_stats=True)
+    assert hasattr(y, "_ipdm_partials")
+    ones = torch.ones(Cout).cuda()
+    c_part = ops.instnorm_plus_coef(y, ones, ones, None)
+    yd = y.double()
+    rstd = 1.0 / torch.sqrt(yd.var(dim=(2, 3), unbiased=False) + 1e-5)
+    assert (c_part[..., 0].double() - yd.mean(dim=(2, 3))).abs().max() < 1e-3            # 1000 +- 6e-5 ulp data
+    assert (c_part[..., 1].double() / rstd - 1).abs().max() < 2e-4
+    c_full = ops.instnorm_plus_coef(y, ones, ones, None)                                   # partials consumed: full pass
+    assert (c_full[..., 1].double() / rstd - 1).abs().max() < 2e-4
+
+
 def test_wino_bx3_statistics_epilogue_unsupported(ops):
     from inverseproblemwithdiffusionmodel_amd import _lib
     lib = _lib.lib
