@@ -73,35 +73,48 @@ __global__ __launch_bounds__(256) void conv3x3_fewin_kernel(const float* __restr
 
 // ---- few output channels: one thread per (b, y, quad) walks all input channels ---------------------------------------------
 // SHFL (W / 4 divides 64): the columns left and right of a thread's quad are the neighbouring lanes' own elements
-// (cross-lane moves instead of six more 4-byte loads per channel: the address path, not HBM, was the limit)
+// (cross-lane moves instead of six more 4-byte loads per channel: the address path, not HBM, was the limit).
+// The image border costs nothing inside the channel loop: rows above / below the image are read from a valid row and
+// accumulate into their own partial sums (top / middle / bottom row of taps), as do the two halo columns; what lies outside
+// the image is dropped when the partial sums are added at the end (fixed order: middle, top, bottom, left, right).
 template <int COUT, bool SHFL>
 __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ out,
                                                              int B, int Cin, int H, int W) {
+  // a workgroup = 64 items x 4 channel groups (wave g takes channels g, g+4, ...: four times the waves in flight of one
+  // thread per item -- 1.75 waves per SIMD left the loads' latency exposed); the four partial sums meet in LDS, added in
+  // group order
+  __shared__ float red[3][COUT][4][64];
   const int Q = W >> 2;
   const long long items = (long long)B * H * Q;
   const long long HW = (long long)H * W;
-  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  for (long long it0 = (long long)blockIdx.x * 64; it0 < items; it0 += (long long)gridDim.x * 64) {
+    const long long it = it0 + lane < items ? it0 + lane : items - 1;       // a tail lane repeats the last item (not stored)
+    const bool live = it0 + lane < items;
     const int q = (int)(it % Q);
     const long long t = it / Q;
     const int y = (int)(t % H);
     const int b = (int)(t / H);
-    float acc[COUT][4];
+    // acc[co][r][j]: taps of kernel row r on the thread's own four columns; hl / hr [co][r]: the halo columns' taps
+    float acc[COUT][3][4], hl[COUT][3], hr[COUT][3];
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) {
-      const float bv = bias ? bias[co] : 0.f;
-      acc[co][0] = bv; acc[co][1] = bv; acc[co][2] = bv; acc[co][3] = bv;
-    }
-    const bool up = y > 0, dn = y < H - 1, lf = q > 0, rt = q < Q - 1;
-    const float* base = x + ((long long)b * Cin * H + y) * W + 4 * q;
-#pragma unroll 4
-    for (int ci = 0; ci < Cin; ++ci) {
-      const float* cp = base + ci * HW;
-      float in[3][6];
+    for (int co = 0; co < COUT; ++co)
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const bool row_ok = r == 0 ? up : (r == 2 ? dn : true);
-        const float* rp = cp + (row_ok ? (r - 1) * W : 0);
+        hl[co][r] = 0.f; hr[co][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[co][r][j] = 0.f;
+      }
+    const bool up = y > 0, dn = y < H - 1, lf = q > 0, rt = q < Q - 1;
+    const float* base = x + ((long long)b * Cin * H + y) * W + 4 * q;
+    const int ro[3] = {up ? -W : 0, 0, dn ? W : 0};
+#pragma unroll 4
+    for (int ci = grp; ci < Cin; ci += 4) {
+      const float* cp = base + ci * HW;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float* rp = cp + ro[r];
         const float4 m = *reinterpret_cast<const float4*>(rp);
         float l, rr;
         if constexpr (SHFL) {
@@ -111,29 +124,60 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(const float* __rest
           l = rp[lf ? -1 : 0];
           rr = rp[rt ? 4 : 3];
         }
-        in[r][0] = (row_ok && lf) ? l : 0.f;
-        in[r][1] = row_ok ? m.x : 0.f; in[r][2] = row_ok ? m.y : 0.f; in[r][3] = row_ok ? m.z : 0.f; in[r][4] = row_ok ? m.w : 0.f;
-        in[r][5] = (row_ok && rt) ? rr : 0.f;
-      }
 #pragma unroll
-      for (int co = 0; co < COUT; ++co) {
-        const float* wp = w + ((long long)co * Cin + ci) * 9;   // wave-uniform: scalar loads
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float wv = wp[r * 3 + c];
-            acc[co][0] = fmaf(wv, in[r][c], acc[co][0]);
-            acc[co][1] = fmaf(wv, in[r][c + 1], acc[co][1]);
-            acc[co][2] = fmaf(wv, in[r][c + 2], acc[co][2]);
-            acc[co][3] = fmaf(wv, in[r][c + 3], acc[co][3]);
-          }
+        for (int co = 0; co < COUT; ++co) {
+          const float* wp = w + ((long long)co * Cin + ci) * 9 + r * 3;   // wave-uniform: scalar loads
+          const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
+          // output column j takes w0 * in[j-1] + w1 * in[j] + w2 * in[j+1]
+          hl[co][r] = fmaf(w0, l, hl[co][r]);
+          acc[co][r][0] = fmaf(w1, m.x, acc[co][r][0]);
+          acc[co][r][0] = fmaf(w2, m.y, acc[co][r][0]);
+          acc[co][r][1] = fmaf(w0, m.x, acc[co][r][1]);
+          acc[co][r][1] = fmaf(w1, m.y, acc[co][r][1]);
+          acc[co][r][1] = fmaf(w2, m.z, acc[co][r][1]);
+          acc[co][r][2] = fmaf(w0, m.y, acc[co][r][2]);
+          acc[co][r][2] = fmaf(w1, m.z, acc[co][r][2]);
+          acc[co][r][2] = fmaf(w2, m.w, acc[co][r][2]);
+          acc[co][r][3] = fmaf(w0, m.z, acc[co][r][3]);
+          acc[co][r][3] = fmaf(w1, m.w, acc[co][r][3]);
+          hr[co][r] = fmaf(w2, rr, hr[co][r]);
+        }
       }
     }
+    float o[COUT][4];
 #pragma unroll
-    for (int co = 0; co < COUT; ++co)
-      *reinterpret_cast<float4*>(out + (((long long)b * COUT + co) * H + y) * W + 4 * q) =
-          make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]);
+    for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = acc[co][1][j];
+        if (up) v += acc[co][0][j];
+        if (dn) v += acc[co][2][j];
+        o[co][j] = v;
+      }
+      float left = hl[co][1], right = hr[co][1];
+      if (up) { left += hl[co][0]; right += hr[co][0]; }
+      if (dn) { left += hl[co][2]; right += hr[co][2]; }
+      if (lf) o[co][0] += left;
+      if (rt) o[co][3] += right;
+    }
+    if (grp > 0) {
+#pragma unroll
+      for (int co = 0; co < COUT; ++co)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[grp - 1][co][j][lane] = o[co][j];
+    }
+    __syncthreads();
+    if (grp == 0 && live) {
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) {
+        const float bv = bias ? bias[co] : 0.f;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = bv + (((o[co][j] + red[0][co][j][lane]) + red[1][co][j][lane]) + red[2][co][j][lane]);
+        *reinterpret_cast<float4*>(out + (((long long)b * COUT + co) * H + y) * W + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    __syncthreads();                                          // red is rewritten by the next round
   }
 }
 
@@ -164,6 +208,7 @@ extern "C" int ipdm_conv3x3_thin_f32(const float* x, const float* w, const float
   } else {
     if (coef) return IPDM_EUNSUPPORTED;          // an input affine on the wide side belongs to the producing layer
     const int Q = W / 4;
+    const int gx = ipdm_ew_grid(items, 64);       // 64 items per workgroup (four channel groups each)
     const bool shfl = Q <= 64 && 64 % Q == 0;     // a row of quads never straddles a wave (items are dealt row-major)
 #define IPDM_FEWOUT(CO)                                                                                                     \
   if (shfl) hipLaunchKernelGGL((conv3x3_fewout_kernel<CO, true>), dim3(gx), dim3(256), 0, s, x, w, bias, out, B, Cin, H, W); \
