@@ -109,8 +109,14 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(const float* __rest
     const bool up = y > 0, dn = y < H - 1, lf = q > 0, rt = q < Q - 1;
     const float* base = x + ((long long)b * Cin * H + y) * W + 4 * q;
     const int ro[3] = {up ? -W : 0, 0, dn ? W : 0};
-#pragma unroll 4
-    for (int ci = grp; ci < Cin; ci += 4) {
+    // four channels per trip, unrolled by hand: the cross-lane moves are convergent operations, which keep hipcc from
+    // unrolling a loop of run-time length itself (it warned "loop not unrolled"), and one channel per trip leaves three
+    // loads in flight per lane
+    for (int ci0 = grp; ci0 < Cin; ci0 += 16)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ci = ci0 + 4 * u;
+      if (ci >= Cin) break;                                   // wave-uniform
       const float* cp = base + ci * HW;
 #pragma unroll
       for (int r = 0; r < 3; ++r) {

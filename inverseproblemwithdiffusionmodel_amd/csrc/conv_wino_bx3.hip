@@ -573,7 +573,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   auto issue_dma = [&](int chunk) {
     if constexpr (KSP) chunk += dma_c0;
     if constexpr (DMA4) {
-      const int soff = (int)(((size_t)dma_b * a.Cin + chunk * X_KC) * HW * 4);
+      [[maybe_unused]] const int soff = (int)(((size_t)dma_b * a.Cin + chunk * X_KC) * HW * 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the 16-byte form only exists for gfx950: keep it out of the host pass
@@ -1384,8 +1384,8 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
     const int64_t nblk = (int64_t)a.B * a.co_tiles;
     static bool poly_attr = false;
     if (!poly_attr) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, true, false, false, false, true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, true, false, false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
       poly_attr = true;
     }
     const int per_xcd = (int)((nblk + 7) / 8);
@@ -1537,8 +1537,8 @@ int conv_wino_bx3_launch_ksplit(ConvArgs a, int ksplit, float* work, hipStream_t
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, true, false, false, true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, true, false, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
     attr_set = true;
   }
   const int per_xcd = (int)((nblk + 7) / 8);
