@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
   //   t = ((sy*d + sx)*THS + tyy)*TWS + txx   covers output pixels (d*(2*tyy+i) + sy, d*(2*txx+j) + sx)
   // and reads input pixels d apart; a 16x16 image is exactly 64 tiles for d = 1, 2 and 4.
   const int d = a.dil;
-  const int TWS = SMALL ? a.W / (2 * d) : 0, THS = SMALL ? a.H / (2 * d) : 0;
+  const int TWS = SMALL ? a.W / (2 * d) : 1, THS = SMALL ? a.H / (2 * d) : 1;   // (wide form: unused)
   const int tile0 = SMALL ? tx * W_TILES : 0;               // tiles_x counts 64-tile groups, tiles_y == 1
   auto tile_origin = [&](int tl, int& py, int& px) {        // top-left OUTPUT pixel of tile tl (SMALL)
     const int txx = tl % TWS;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
   const int tyl = mytile / W_TX, txl = mytile % W_TX;
   // 4x4 patch addresses = (clamped row offset) + (clamped column offset); padding is zero-selected after the load
   int row_off[4], col_off[4];
-  unsigned p_valid = 0, rv = 0, cv = 0;
+  unsigned rv = 0, cv = 0;
   int my_py = 0, my_px = 0;
   bool my_tile_ok = true;
   if constexpr (SMALL) {
@@ -124,7 +124,6 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const bool ok = (((rv >> (e / 4)) & (cv >> (e % 4))) & 1u) != 0;
-    p_valid |= ok ? (1u << e) : 0u;
     p_boff[e] = ok ? (row_off[e / 4] + col_off[e % 4]) * 4 : 0x7ffffff0;
   }
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
   // SMALL: 64 consecutive tiles of the image's linear tile space; a dilation-d convolution is d*d undilated ones on
   // the d-subsampled images: tile t = ((sy*d + sx)*THS + tyy)*TWS + txx covers output (d*(2*tyy+i)+sy, d*(2*txx+j)+sx)
   const int d = a.dil;
-  const int TWS = SMALL ? a.W / (2 * d) : 0, THS = SMALL ? a.H / (2 * d) : 0;
+  const int TWS = SMALL ? a.W / (2 * d) : 1, THS = SMALL ? a.H / (2 * d) : 1;   // (wide form: unused)
   const int tile0 = SMALL ? tx * X_TILES : 0;
   auto tile_origin = [&](int tl, int& py, int& px) {
     const int txx = tl % TWS;
