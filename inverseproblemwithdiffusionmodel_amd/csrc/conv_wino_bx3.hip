@@ -765,9 +765,11 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           f32x16 v = acc[pi][c][tg];
+#ifndef IPDM_PROBE_HALF_MFMA
           v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][2], bh, v, 0, 0, 0);
           v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bl, v, 0, 0, 0);
           v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][1], bm, v, 0, 0, 0);
+#endif
           v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][1], bh, v, 0, 0, 0);
           v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bm, v, 0, 0, 0);
           v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bh, v, 0, 0, 0);

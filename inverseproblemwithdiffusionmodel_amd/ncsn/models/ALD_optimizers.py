@@ -204,7 +204,10 @@ class ALDInvSegProximalRealImag(ALDOptimizer):
     @torch.no_grad()
     def __call__(self, **kwargs):
         """kwargs: label, lamda, save_dir, lr_scaled, seg_mode (+ noise_fn, seed, sample_offset, verbose, use_graph,
-        n_levels/start_level to run a slice of the schedule)"""
+        n_levels/start_level to run a slice of the schedule, snapshot_its: iterations of this call whose incoming state is
+        kept in self._snapshots)"""
+        if self._hooks_overridden():
+            return self._call_with_hooks(**kwargs)
         sc_mode = self._check_fast_path(kwargs)
         sigmas = self.sigmas
         n_steps_each, step_lr = self.params["n_steps_each"], self.params["step_lr"]
@@ -255,10 +258,14 @@ class ALDInvSegProximalRealImag(ALDOptimizer):
         label_table = torch.from_numpy(np.repeat(lv[:, None], 2 * B, axis=1)).to(dev)
 
         graph = None
+        snap_its = set(kwargs.get("snapshot_its") or ())           # iteration k (of this call) -> state BEFORE it runs
+        self._snapshots = {}
         for k in range(n_it):
             c = int(lv[k])
             if verbose and k % n_steps_each == 0 and c % max(L // 10, 1) == 0:
                 print(f"{c + 1}/{L}")
+            if k in snap_its:
+                self._snapshots[k] = torch.complex(x[:B], x[B:]).to("cpu")
             st["sched_dev"].copy_(table_dev[k], non_blocking=True)
             st["labels"].copy_(label_table[k], non_blocking=True)
             if noise_fn is not None:
@@ -287,14 +294,68 @@ class ALDInvSegProximalRealImag(ALDOptimizer):
             self._iteration(st)
         return g
 
+    # -- the reference's hook points.  The fused iteration above does their work inside its kernels and never calls them;
+    #    a subclass that OVERRIDES either one gets the reference's loop (:204-252) instead, hook by hook, eagerly --
+    def _hooks_overridden(self):
+        base, t = ALDInvSegProximalRealImag, type(self)
+        return t.adjust_grad is not base.adjust_grad or t.post_processing is not base.post_processing
+
     def adjust_grad(self, grad, m_mod, **kwargs):
-        return grad
+        """reference hook (:272-286): grad + compute_seg_grad(seg, m_mod, label, seg_mode) / sigma * seg_lamda"""
+        if not self._seg_active():
+            return grad                                             # weight 0 at every level: the term is 0 (:27-28)
+        label = kwargs["label"].to(m_mod.device, torch.int64)
+        if label.shape[0] != m_mod.shape[0]:
+            label = label.expand(m_mod.shape[0], *label.shape[1:])
+        gseg = self.seg.loglh_grad(m_mod, label.contiguous(), kwargs.get("seg_mode", "full"))
+        return ops.axpby(grad, gseg, 1.0, float(kwargs["seg_lamda"]) / float(kwargs["sigma"]))
 
     def post_processing(self, x_mod_real, x_mod_imag, **kwargs):
         """reference hook (:288-327): proximal(x, measurement, alpha * lr_scaled, 1.) on separate planes"""
         x = torch.complex(x_mod_real, x_mod_imag)
-        x = self.proximal(x, self.measurement.to(x.device), kwargs["alpha"] * kwargs["lr_scaled"], 1.)
+        x = self.proximal(x, self.measurement.to(x.device), kwargs["alpha"] * kwargs.get("lr_scaled", 1.), 1.)
         return torch.real(x).contiguous(), torch.imag(x).contiguous()
+
+    def _call_with_hooks(self, **kwargs):
+        """the reference's loop with its insertion points honoured (a subclass overrides adjust_grad / post_processing):
+        score network on both planes as one batch, adjust_grad per plane, the Langevin kernel, post_processing.  Same
+        noise keying as the fused iteration (Philox by (seed, sample, iteration, plane), or noise_fn)."""
+        if self._seg_active() and not hasattr(self.seg, "loglh_grad"):
+            raise NotImplementedError("segmentation-likelihood guidance needs ncsn.models.seg_unet.UNet.loglh_grad")
+        sigmas = self.sigmas
+        n_steps_each, step_lr = self.params["n_steps_each"], self.params["step_lr"]
+        noise_fn, dev = kwargs.get("noise_fn"), self.device
+        seed, sample_offset = kwargs.get("seed", 0), kwargs.get("sample_offset", 0)
+        meas = self.measurement.to(dev).to(torch.complex64).contiguous()
+        x0 = kwargs.get("x_init")
+        x0 = self.linear_tfm.conj_op(meas) if x0 is None else x0.to(dev)
+        B = x0.shape[0]
+        x_re, x_im = x0.real.contiguous().float(), x0.imag.contiguous().float()
+        steps, noise_scales = step_schedule(sigmas, step_lr)
+        L = len(sigmas)
+        lv0 = kwargs.get("start_level", 0)
+        lv1 = L if kwargs.get("n_levels") is None else min(L, lv0 + kwargs["n_levels"])
+        hook_kw = {k: v for k, v in kwargs.items() if k not in ("sigma", "seg_lamda", "alpha")}
+        it = lv0 * n_steps_each
+        for c in range(lv0, lv1):
+            labels = torch.full((2 * B,), c, dtype=torch.long, device=dev)
+            for _ in range(n_steps_each):
+                grad = self.scorenet(torch.cat([x_re, x_im], dim=0), labels)
+                g_re = self.adjust_grad(grad[:B], x_re, sigma=sigmas[c], seg_lamda=self.lh_weights[c], **hook_kw)
+                g_im = self.adjust_grad(grad[B:], x_im, sigma=sigmas[c], seg_lamda=self.lh_weights[c], **hook_kw)
+                for plane, (xp, gp) in enumerate(((x_re, g_re), (x_im, g_im))):
+                    nz = (noise_fn(xp).to(dev) if noise_fn is not None else
+                          ops.philox_normal(tuple(xp.shape), dev, seed=seed, sample_offset=sample_offset, step_id=it, plane=plane))
+                    ops.langevin_step(xp, gp.contiguous(), float(steps[c]), float(noise_scales[c]), noise=nz)
+                x_re, x_im = self.post_processing(x_re, x_im, alpha=step_lr, sigma=sigmas[c], **hook_kw)
+                x_re, x_im = x_re.contiguous().float(), x_im.contiguous().float()
+                it += 1
+        if self.params["denoise"] and lv1 == L:
+            labels = torch.full((2 * B,), L - 1, dtype=torch.long, device=dev)
+            x = torch.cat([x_re, x_im], dim=0).contiguous()
+            ops.langevin_step(x, self.scorenet(x, labels), float(sigmas.detach().cpu()[-1] ** 2), 0.0, noise=torch.zeros_like(x))
+            x_re, x_im = x[:B], x[B:]
+        return [torch.complex(x_re, x_im).to("cpu")]
 
 
 class ALD2DTime(ALDOptimizer):

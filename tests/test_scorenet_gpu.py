@@ -298,6 +298,99 @@ def test_headline_trajectory_vs_reference(pkg, golden, full_net, tag, use_graph)
     assert np.linalg.norm(upd_ref) > 0.05 * np.linalg.norm(x0)                              # the run moved the image
 
 
+G29_SNAPS = {"head": (), "long": (36, 100, 200)}
+
+
+def _g29_run(pkg, full_net, g, tag, use_graph=True, impl=None):
+    """the product sampler on one g29 window: the full 2311-level schedule, start_level / n_levels select the window
+    (true step sizes), the fixture's seeded noise stream; -> (final x, {iteration: state}, x_init)"""
+    from inverseproblemwithdiffusionmodel_amd import ops
+    from oracle import kspace as okspace
+    cfg, net = full_net
+    lv0, n_lv, seed, n_calls, n_sum = g[f"{tag}_meta"]
+    lv0, n_lv = int(lv0), int(n_lv)
+    B, H, W = 2, 128, 128
+    op = pkg.uf.SENSE("exp", 4, 40, 0.04, (1, H, W), seed=0)
+    assert np.array_equal(op.random_under_fourier.mask.numpy(), g["mask"])
+    sig_all = torch.from_numpy(okspace.get_sigmas(348, 0.01, 2311)).cuda()
+    meas = torch.from_numpy(g["measurement_1"]).repeat(1, B, 1, 1, 1).cuda()
+    params = dict(n_steps_each=3, step_lr=9e-7, denoise=False, final_only=True)
+    sampler = pkg.ald.ALDInvSegProximalRealImag(pkg.prox.get_proximal("L2Penalty")(op), 1.0, "linear", (B, 1, H, W), net,
+                                                sig_all, params, cfg, meas, op, seg=None, device=torch.device("cuda"))
+    noise = _SeededNoise(seed)
+    old = ops.CONV_IMPL
+    try:
+        if impl is not None:
+            ops.CONV_IMPL = impl
+        x = sampler(label=None, lamda=0.1, save_dir=None, lr_scaled=1.0, seg_mode="full", noise_fn=noise,
+                    use_graph=use_graph, start_level=lv0, n_levels=n_lv, snapshot_its=G29_SNAPS[tag])[0].numpy()
+    finally:
+        ops.CONV_IMPL = old
+    assert noise.calls == int(n_calls) == 6 * n_lv and abs(noise.total - float(n_sum)) < 5e-2      # the reference's stream
+    snaps = {k: v.numpy() for k, v in sampler._snapshots.items()}
+    return x, snaps, op.conj_op(meas).cpu().numpy()
+
+
+@pytest.mark.parametrize("tag,use_graph", [("head", True), ("head", False), ("long", True), ("long", False)])
+def test_headline_head_and_long_window_vs_reference(pkg, golden, full_net, tag, use_graph):
+    """The headline configuration against the REFERENCE's own runs at the schedule's TRUE step sizes
+    (tests/golden/g29_headline_long.npz, make_golden_r3.py): `head` = noise levels 0..11 (sigma ~ 348, step
+    9e-7 (348/0.01)^2 ~ 1.09e3, noise scale ~ 47: the state grows to |x| ~ 1e3 -- where rounding differences are amplified
+    most), `long` = 300 CONSECUTIVE iterations from level 1100 (sigma 2.4 -> 1.5; step 0.05 -> 0.02).  Tolerance:
+    north_star's NRMSE / SSIM 1e-3 per sample at the end of the window and at every recorded intermediate state."""
+    g = golden("g29_headline_long")
+    x, snaps, x0 = _g29_run(pkg, full_net, g, tag, use_graph)
+    ref = g[f"{tag}_x"]
+    assert x.shape == ref.shape == (2, 1, 128, 128) and np.isfinite(x).all()
+    checks = [(x, ref)] + [(snaps[k], g[f"{tag}_x_it{k}"]) for k in G29_SNAPS[tag]]
+    for a, r in checks:
+        for b in range(2):
+            assert metrics.nrmse(np.abs(a[b]), np.abs(r[b])) < 1e-3
+            assert abs(metrics.ssim(np.abs(a[b, 0]), np.abs(r[b, 0]), data_range=float(np.abs(r[b]).max())) - 1.0) < 1e-3
+    assert np.linalg.norm(ref - x0) > 0.5 * np.linalg.norm(x0)                                 # the run moved the image
+    np.testing.assert_allclose(x, ref, atol=2e-3 * np.abs(ref).max())
+
+
+def test_error_growth_table(pkg, golden, full_net):
+    """SURVEY.md section 7's sensitivity study as numbers: NRMSE of the complex state against the reference (fp32 torch CPU)
+    after 36 / 100 / 200 / 300 iterations of the `long` window, for the default kernel family, the exact-fp32-MFMA family,
+    and the float64 CPU oracle (g29f_sensitivity_f64.npz: NOT the reference -- it measures how far fp32 rounding alone
+    moves the trajectory).  Written to gpurun_out/r03_error_growth.json; DESIGN.md section 2 carries the table."""
+    import json, os
+    from inverseproblemwithdiffusionmodel_amd import ops
+    g, g64 = golden("g29_headline_long"), golden("g29f_sensitivity_f64")
+
+    def err(a, r):
+        return float(np.linalg.norm(a - r) / np.linalg.norm(r))
+
+    table = {}
+    its = list(G29_SNAPS["long"]) + [300]
+    refs = {k: g[f"long_x_it{k}"] for k in G29_SNAPS["long"]}
+    refs[300] = g["long_x"]
+    for name, impl in [(ops.CONV_IMPL, None), ("f32", "f32")] + ([("bx3", "bx3")] if ops.CONV_IMPL != "bx3" else []):
+        x, snaps, _ = _g29_run(pkg, full_net, g, "long", True, impl)
+        snaps[300] = x
+        table[name + "_vs_reference"] = {k: err(snaps[k], refs[k]) for k in its}
+    f64 = {k: g64[f"long_x_it{k}"] for k in G29_SNAPS["long"]}
+    f64[300] = g64["long_x"]
+    table["float64_oracle_vs_reference"] = {k: err(f64[k], refs[k]) for k in its}
+    xh, _, _ = _g29_run(pkg, full_net, g, "head", True)
+    table["head_36_iterations"] = {ops.CONV_IMPL + "_vs_reference": err(xh, g["head_x"]),
+                                   "float64_oracle_vs_reference": err(g64["head_x"], g["head_x"])}
+    print(json.dumps(table, indent=1))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/r03_error_growth.json", "w") as f:
+            json.dump(table, f, indent=1)
+    except OSError:
+        pass
+    # fp32 rounding alone (float64 oracle vs the fp32 reference) sets the scale; the HIP path must not be an order worse
+    for name, row in table.items():
+        if name.endswith("_vs_reference") and not name.startswith("float64"):
+            for k in its:
+                assert row[k] < max(1e-3, 10 * table["float64_oracle_vs_reference"][k]), (name, k, row[k])
+
+
 @pytest.mark.parametrize("name,cls,size", [("v2_32", "NCSNv2", 32), ("v2_28", "NCSNv2", 28), ("deeper_32", "NCSNv2Deeper", 32)])
 def test_ncsnv2_variants_golden(pkg, golden, name, cls, size):
     """NCSNv2 (incl. the 28-pixel branch of ncsnv2.py:50-56 = BASELINE config 1's literal size) and NCSNv2Deeper vs the
