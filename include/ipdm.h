@@ -35,7 +35,7 @@ extern "C" {
 #define IPDM_ACT_SWISH 4
 
 /* library identification: returns IPDM_ABI_VERSION, writes the gfx arch string the kernels were built for */
-#define IPDM_ABI_VERSION 2
+#define IPDM_ABI_VERSION 3
 int ipdm_abi_version(void);
 const char* ipdm_build_arch(void);
 
@@ -340,6 +340,38 @@ int ipdm_conv2d_wino_bx3_splitk_f32(const float* x, const void* U, const float* 
                                     int ksplit, float* work, void* stream);
 int ipdm_conv2d_wino_bx3_stats_partials(int Cin, int Cout, int H, int W, int dilation, int pool2);
 int ipdm_conv2d_wino_bx3_stats_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
+                                   float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
+                                   int pool2, float* stats, void* stream);
+/* ---- "f16x2": the split-operand kernels above with TWO fp16 pieces per fp32 operand and THREE v_mfma_f32_32x32x16_f16 per
+ * product (fp32 accumulation) -- half the matrix-core work and two thirds of the weight bytes of the three-way bf16 split.
+ * fp32-faithful (error against float64 at or below the bf16 split's and the exact-fp32 kernel's on the networks' layer
+ * shapes) under a RANGE contract: weights are scaled per output channel by a power of two at pack time (the inverse scale
+ * rides in the blob); activations must satisfy |x| < 65504, and |x| < 16376 for the Winograd calls -- beyond that the result
+ * is NaN / inf (never a wrong finite number); the bx3 calls keep the whole fp32 exponent range.  Same arguments, semantics
+ * and replaced reference interface (torch.nn.Conv2d / Conv3d inside ncsn/models/layers.py:28-60) as their bx3 twins; the
+ * shape rules (ipdm_conv_bx3_splitk, ipdm_conv2d_wino_bx3_supported / _splitk / _stats_partials) are shared. */
+int64_t ipdm_conv_hx2_weight_bytes(int Cout, int Cin, int k);
+int ipdm_conv_hx2_pack_weight(const float* w /* [Cout][Cin][k][k] or [Cout][Cin][3][3][3] */, void* packed, int Cout,
+                              int Cin, int k, void* stream);
+int ipdm_conv2d_hx2_f32(const float* x, const void* packed, const float* bias, const float* coef, int act,
+                        const float* residual, float* out, float* out_act, int act_out,
+                        int B, int Cin, int Cout, int H, int W, int k, int dilation, void* stream);
+int ipdm_conv3d_hx2_f32(const float* x, const void* packed, const float* bias, const float* coef, int act,
+                        const float* residual, float* out, float* out_act, int act_out,
+                        int B, int Cin, int Cout, int D, int H, int W, int k, int dilation, void* stream);
+int ipdm_conv_hx2_splitk_f32(const float* x, const void* packed, const float* bias, const float* coef, int act,
+                             const float* residual, float* out, float* out_act, int act_out,
+                             int B, int Cin, int Cout, int D, int H, int W, int k, int dilation, int volume, int ksplit,
+                             float* work, void* stream);
+int64_t ipdm_conv_wino_hx2_weight_bytes(int Cout, int Cin);
+int ipdm_conv_wino_hx2_pack_weight(const float* w /* [Cout][Cin][3][3] */, void* U, int Cout, int Cin, void* stream);
+int ipdm_conv2d_wino_hx2_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
+                             float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
+                             int pool2, void* stream);
+int ipdm_conv2d_wino_hx2_splitk_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
+                                    float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
+                                    int ksplit, float* work, void* stream);
+int ipdm_conv2d_wino_hx2_stats_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
                                    float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
                                    int pool2, float* stats, void* stream);
 int ipdm_instnorm_plus_coef_partials_f32(const float* partials, int P, const float* alpha, const float* gamma,

@@ -81,6 +81,16 @@ SIGNATURES = {
     "ipdm_conv2d_wino_bx3_splitk": [c_int, c_int, c_int, c_int, c_int],
     "ipdm_conv2d_wino_bx3_splitk_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "ipdm_conv2d_wino_bx3_stats_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
+    "ipdm_conv_hx2_weight_bytes": [c_int, c_int, c_int],
+    "ipdm_conv_hx2_pack_weight": [P, P, c_int, c_int, c_int, P],
+    "ipdm_conv2d_hx2_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 7 + [P],
+    "ipdm_conv3d_hx2_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 8 + [P],
+    "ipdm_conv_hx2_splitk_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 10 + [P, P],
+    "ipdm_conv_wino_hx2_weight_bytes": [c_int, c_int],
+    "ipdm_conv_wino_hx2_pack_weight": [P, P, c_int, c_int, P],
+    "ipdm_conv2d_wino_hx2_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "ipdm_conv2d_wino_hx2_splitk_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
+    "ipdm_conv2d_wino_hx2_stats_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "ipdm_instnorm_plus_coef_partials_f32": [P, c_int, P, P, P, P, c_int, c_int, P],
     "ipdm_zero_insert2_f32": [P, P, c_int, c_int, c_int, P],
     "ipdm_subsample2_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
@@ -94,7 +104,8 @@ SIGNATURES = {
     "ipdm_ssim_f32": [P, P, P, c_int, c_int, c_int, c_int, ctypes.c_double, P],
 }
 _RESTYPES = {"ipdm_build_arch": c_char_p, "ipdm_fft2c_workspace_bytes": c_int64, "ipdm_sense_workspace_bytes": c_int64, "ipdm_conv_bx3_weight_bytes": c_int64,
-             "ipdm_conv_wino_bx3_weight_bytes": c_int64}
+             "ipdm_conv_wino_bx3_weight_bytes": c_int64, "ipdm_conv_hx2_weight_bytes": c_int64,
+             "ipdm_conv_wino_hx2_weight_bytes": c_int64}
 
 IPDM_EINVAL = -1
 IPDM_EUNSUPPORTED = -2

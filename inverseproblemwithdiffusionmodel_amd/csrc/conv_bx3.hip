@@ -29,8 +29,9 @@ namespace ipdm_conv {
 
 constexpr int BX3_KG = 8;       // K chunks (of 16 input channels) per accumulation group of the 16-pixel configurations
 
-template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS>
+template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS, bool HX = false>
 struct BxCfg {
+  static constexpr int NPC = HX ? 2 : 3;                     // operand pieces (conv_kernel.h: f16x2 / three-way bf16)
   static constexpr int TAPS = KS * KS;
   static constexpr int CO_T = 32 * NCT * WCO;
   static constexpr int ROWS_PER_TILE = 32 / PW;
@@ -42,14 +43,15 @@ struct BxCfg {
   // disjoint banks for ds_read_b128's lane groups
   static constexpr int PITCH = PW == 32 ? PWP : (PWP + 15) / 16 * 16;
   static constexpr int PLANE = PHP * PITCH;                  // 16-byte units
-  static constexpr int STAGE = 6 * PLANE;                    // [piece 3][h 2][PLANE]
+  static constexpr int STAGE = 2 * NPC * PLANE;              // [piece][h 2][PLANE]
   static constexpr int ITEMS = (2 * PHP * PWP + 255) / 256;  // (pixel, 8-channel group) items per thread
   static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE * 16;
 };
 
-template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS, bool FAST>
+template <bool HX, int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS, bool FAST>
 __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
-  using C = BxCfg<NCT, NPT, WCO, WPX, PW, DMAX, KS>;
+  using C = BxCfg<NCT, NPT, WCO, WPX, PW, DMAX, KS, HX>;
+  constexpr int NPC = C::NPC, FRAG = 64 * NPC;               // FRAG: 16-byte units per (tap, chunk, channel tile)
   static_assert(WCO * WPX == 4, "four waves per workgroup");
   extern __shared__ __align__(16) uint4 lds4[];
 
@@ -181,32 +183,39 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
         }
         v[q] = val;
       }
-      bf16x8 ph, pm, pl;
-      split3(v, ph, pm, pl);
-      st[it_lds[i]] = __builtin_bit_cast(uint4, ph);
-      st[2 * C::PLANE + it_lds[i]] = __builtin_bit_cast(uint4, pm);
-      st[4 * C::PLANE + it_lds[i]] = __builtin_bit_cast(uint4, pl);
+      if constexpr (HX) {
+        uint4 ph, pl;
+        split2(v, ph, pl);
+        st[it_lds[i]] = ph;
+        st[2 * C::PLANE + it_lds[i]] = pl;
+      } else {
+        bf16x8 ph, pm, pl;
+        split3(v, ph, pm, pl);
+        st[it_lds[i]] = __builtin_bit_cast(uint4, ph);
+        st[2 * C::PLANE + it_lds[i]] = __builtin_bit_cast(uint4, pm);
+        st[4 * C::PLANE + it_lds[i]] = __builtin_bit_cast(uint4, pl);
+      }
     }
   };
 
   // ---- A fragments: global -> VGPR, [tapidx][cc][ct][piece][lane] in 16-byte units ----
   const uint4* wq = reinterpret_cast<const uint4*>(a.wt);
   const int ct0 = (co_tile * WCO + wco) * NCT;
-  const size_t tap_stride = (size_t)n_cc * n_ct * 192;
+  const size_t tap_stride = (size_t)n_cc * n_ct * FRAG;
   int ct_ofs[NCT];
 #pragma unroll
-  for (int m = 0; m < NCT; ++m) ct_ofs[m] = (ct0 + m < n_ct ? ct0 + m : n_ct - 1) * 192 + lane;   // ragged: reload a valid one
+  for (int m = 0; m < NCT; ++m) ct_ofs[m] = (ct0 + m < n_ct ? ct0 + m : n_ct - 1) * FRAG + lane;  // ragged: reload a valid one
   auto a_chunk_ptr = [&](int ch) {
     int kz, c0;
     chunk_kz_c0(ch, kz, c0);
-    return wq + ((size_t)kz * C::TAPS * n_cc + (c0 >> 4)) * n_ct * 192;
+    return wq + ((size_t)kz * C::TAPS * n_cc + (c0 >> 4)) * n_ct * FRAG;
   };
-  auto load_A = [&](bf16x8 (&fr)[NCT][3], const uint4* base, int tap) {
+  auto load_A = [&](uint4 (&fr)[NCT][NPC], const uint4* base, int tap) {
     const uint4* p = base + tap * tap_stride;
 #pragma unroll
     for (int m = 0; m < NCT; ++m)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) fr[m][s] = __builtin_bit_cast(bf16x8, p[ct_ofs[m] + s * 64]);
+      for (int s = 0; s < NPC; ++s) fr[m][s] = p[ct_ofs[m] + s * 64];
   };
 
   f32x16 acc[NCT][NPT];
@@ -226,8 +235,8 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) tot[m][n][r] = 0.f;
   }
-  bf16x8 afr[2][NCT][3];
-  bf16x8 bfr[2][3];
+  uint4 afr[2][NCT][NPC];
+  uint4 bfr[2][NPC];
   const int c_first = c_begin < n_chunks ? c_begin : n_chunks - 1;   // empty share: stage a valid chunk, use none
   load_A(afr[0], a_chunk_ptr(c_first), 0);
   load_chunk(c_first);
@@ -237,14 +246,13 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
   if (a.dbg) t1 = __builtin_amdgcn_s_memtime();
   constexpr int STEPS = C::TAPS * NPT;
   // operand reads of step s = (tap, pixel tile n): one ds_read_b128 per piece at the tap-shifted pixel
-  auto load_B = [&](bf16x8 (&fr)[3], const uint4* cur, auto sc) {
+  auto load_B = [&](uint4 (&fr)[NPC], const uint4* cur, auto sc) {
     constexpr int st = decltype(sc)::value;
     constexpr int tap = st / NPT, n = st % NPT;
     constexpr int dy = KS == 3 ? tap / 3 - 1 : 0, dx = KS == 3 ? tap % 3 - 1 : 0;
     const uint4* bp = cur + b_base[n] + (dy * C::PITCH + dx) * d;
-    fr[0] = __builtin_bit_cast(bf16x8, bp[0]);
-    fr[1] = __builtin_bit_cast(bf16x8, bp[2 * C::PLANE]);
-    fr[2] = __builtin_bit_cast(bf16x8, bp[4 * C::PLANE]);
+#pragma unroll
+    for (int s = 0; s < NPC; ++s) fr[s] = bp[2 * s * C::PLANE];
   };
 
   for (int ch = c_begin; ch < c_end; ++ch) {
@@ -266,29 +274,44 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
         if constexpr (tap + 1 < C::TAPS) load_A(afr[(tap + 1) & 1], a_cur, tap + 1);
         else load_A(afr[(tap + 1) & 1], a_nxt, 0);
       }
-      const bf16x8 bh = bfr[st & 1][0], bm = bfr[st & 1][1], bl = bfr[st & 1][2];
+      if constexpr (HX) {
+        const f16x8 bh = __builtin_bit_cast(f16x8, bfr[st & 1][0]), bl = __builtin_bit_cast(f16x8, bfr[st & 1][1]);
 #pragma unroll
-      for (int m = 0; m < NCT; ++m) {
-        const bf16x8 ah = afr[tap & 1][m][0], am = afr[tap & 1][m][1], al = afr[tap & 1][m][2];
-        f32x16 c = acc[m][n];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-        acc[m][n] = c;
+        for (int m = 0; m < NCT; ++m) {
+          const f16x8 ah = __builtin_bit_cast(f16x8, afr[tap & 1][m][0]), al = __builtin_bit_cast(f16x8, afr[tap & 1][m][1]);
+          f32x16 c = acc[m][n];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+          acc[m][n] = c;
+        }
+      } else {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bfr[st & 1][0]), bm = __builtin_bit_cast(bf16x8, bfr[st & 1][1]),
+                     bl = __builtin_bit_cast(bf16x8, bfr[st & 1][NPC - 1]);
+#pragma unroll
+        for (int m = 0; m < NCT; ++m) {
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, afr[tap & 1][m][0]), am = __builtin_bit_cast(bf16x8, afr[tap & 1][m][1]),
+                       al = __builtin_bit_cast(bf16x8, afr[tap & 1][m][NPC - 1]);
+          f32x16 c = acc[m][n];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+          acc[m][n] = c;
+        }
       }
-      if constexpr (st + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);          // DS reads first
-      if constexpr (n == 0) __builtin_amdgcn_sched_group_barrier(0x020, 3 * NCT, 0);            // then the A loads
-      __builtin_amdgcn_sched_group_barrier(0x008, 6 * NCT, 0);                                  // then the MFMAs
+      if constexpr (st + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, NPC, 0);        // DS reads first
+      if constexpr (n == 0) __builtin_amdgcn_sched_group_barrier(0x020, NPC * NCT, 0);          // then the A loads
+      __builtin_amdgcn_sched_group_barrier(0x008, (HX ? 3 : 6) * NCT, 0);                       // then the MFMAs
       __builtin_amdgcn_sched_barrier(0);
     });
     if constexpr ((C::TAPS & 1) == 1) {            // the prefetched tap-0 fragments of the next chunk sit in slot 1
 #pragma unroll
       for (int m = 0; m < NCT; ++m)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) afr[0][m][s] = afr[1][m][s];
+        for (int s = 0; s < NPC; ++s) afr[0][m][s] = afr[1][m][s];
     }
     if constexpr (PW == 16) {
       if (((ch + 1) % BX3_KG) == 0 || !more) {     // end of an accumulation group (uniform)
@@ -321,13 +344,17 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
   const float* const res_p = has_res ? a.residual : a.wt;
   const float* const bias_p = has_bias ? a.bias : a.wt;
   const size_t co_stride = has_res ? (size_t)a.D * HW : 0;
+  // f16x2: the channels' inverse weight scales sit behind the fragments ([n_ct * 32] floats)
+  const float* const scale_p = HX ? reinterpret_cast<const float*>(wq + (size_t)(a.kd == 3 ? 3 : 1) * C::TAPS * tap_stride) : a.wt;
   float bv[NCT][16];
+  [[maybe_unused]] float sv[NCT][16];
 #pragma unroll
   for (int m = 0; m < NCT; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + (wco * NCT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       bv[m][r] = bias_p[has_bias ? (co < a.Cout ? co : a.Cout - 1) : 0];
+      if constexpr (HX) sv[m][r] = scale_p[co < n_ct * 32 ? co : 0];
     }
   constexpr int NBATCH = NPT * NCT;
   float rv[2][16];
@@ -355,7 +382,10 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
 #pragma unroll
   for (int m = 0; m < NCT; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bv[m][r]));
+    for (int r = 0; r < 16; ++r) {
+      asm volatile("" : "+v"(bv[m][r]));
+      if constexpr (HX) asm volatile("" : "+v"(sv[m][r]));
+    }
   load_res(std::integral_constant<int, 0>{});
   static_for<NBATCH>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
@@ -377,6 +407,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
           float v;
           if constexpr (PW == 16) v = tot[m][n][r];
           else v = acc[m][n][r];
+          if constexpr (HX) v *= sv[m][r];
           if (!finish) {
             a.partial[(size_t)ks * a.B * a.Cout * cs + o] = v;
             continue;
@@ -399,15 +430,15 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
   }
 }
 
-template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS, bool FAST>
+template <bool HX, int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS, bool FAST>
 int launch_bx3(ConvArgs a, hipStream_t s) {
-  using C = BxCfg<NCT, NPT, WCO, WPX, PW, DMAX, KS>;
+  using C = BxCfg<NCT, NPT, WCO, WPX, PW, DMAX, KS, HX>;
   a.tiles_x = (a.W + PW - 1) / PW;
   a.tiles_y = (a.H + C::PH - 1) / C::PH;
   a.co_tiles = (a.Cout + C::CO_T - 1) / C::CO_T;
   const int64_t nblk = (int64_t)a.B * a.D * a.tiles_x * a.tiles_y * a.co_tiles * a.ksplit;
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
-  auto kern = conv_bx3_kernel<NCT, NPT, WCO, WPX, PW, DMAX, KS, FAST>;
+  auto kern = conv_bx3_kernel<HX, NCT, NPT, WCO, WPX, PW, DMAX, KS, FAST>;
   static bool attr_set = false;
   if (!attr_set) {
     if (C::LDS_BYTES > 64 * 1024) {
@@ -421,14 +452,19 @@ int launch_bx3(ConvArgs a, hipStream_t s) {
   return ipdm_launch_status();
 }
 
-template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX>
-int launch_bx3_cfg(const ConvArgs& a, int ks, hipStream_t s) {
+template <bool HX, int NCT, int NPT, int WCO, int WPX, int PW, int DMAX>
+int launch_bx3_cfg_t(const ConvArgs& a, int ks, hipStream_t s) {
   const bool fast = a.Cin % 16 == 0 && a.act == IPDM_ACT_NONE && !a.coef;
   if (ks == 3) {
-    return fast ? launch_bx3<NCT, NPT, WCO, WPX, PW, DMAX, 3, true>(a, s)
-                : launch_bx3<NCT, NPT, WCO, WPX, PW, DMAX, 3, false>(a, s);
+    return fast ? launch_bx3<HX, NCT, NPT, WCO, WPX, PW, DMAX, 3, true>(a, s)
+                : launch_bx3<HX, NCT, NPT, WCO, WPX, PW, DMAX, 3, false>(a, s);
   }
-  return fast ? launch_bx3<NCT, NPT, WCO, WPX, PW, 1, 1, true>(a, s) : launch_bx3<NCT, NPT, WCO, WPX, PW, 1, 1, false>(a, s);
+  return fast ? launch_bx3<HX, NCT, NPT, WCO, WPX, PW, 1, 1, true>(a, s) : launch_bx3<HX, NCT, NPT, WCO, WPX, PW, 1, 1, false>(a, s);
+}
+template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX>
+int launch_bx3_cfg(const ConvArgs& a, int ks, hipStream_t s) {
+  return a.hx ? launch_bx3_cfg_t<true, NCT, NPT, WCO, WPX, PW, DMAX>(a, ks, s)
+              : launch_bx3_cfg_t<false, NCT, NPT, WCO, WPX, PW, DMAX>(a, ks, s);
 }
 
 static int bx3_forced_cfg() {
@@ -509,9 +545,71 @@ __global__ __launch_bounds__(256) void bx3_pack_kernel(const float* __restrict__
   }
 }
 
+// ---- f16x2 weights (conv_kernel.h): per-output-channel power-of-two scale, two fp16 pieces
+//      [tap][ci/16][co/32][piece 2][h][r][8], followed by the inverse scales [n_ct * 32] (fp32) ----
+__global__ __launch_bounds__(256) void hx2_scale_kernel(const float* __restrict__ w, float* __restrict__ inv_scale, int Cout,
+                                                        int64_t per_co) {
+  __shared__ float red[256];
+  const int co = blockIdx.x;
+  float m = 0.f;
+  if (co < Cout)
+    for (int64_t i = threadIdx.x; i < per_co; i += 256) m = fmaxf(m, fabsf(w[(int64_t)co * per_co + i]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int e = 0;
+    const float mx = red[0];
+    const bool ok = mx > 0.f && mx < INFINITY;
+    if (ok) (void)frexpf(mx, &e);                            // mx = f * 2^e, f in [0.5, 1): mx * 2^(14 - e) in [2^13, 2^14)
+    inv_scale[co] = ok ? ldexpf(1.f, e - 14) : 1.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void hx2_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                       const float* __restrict__ inv_scale, int Cout, int Cin, int kk, int n_cc,
+                                                       int n_ct) {
+  const int64_t total = (int64_t)kk * n_cc * n_ct * 512;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int q = (int)(i & 7), r = (int)((i >> 3) & 31), h = (int)((i >> 8) & 1);
+    const int64_t rest = i >> 9;
+    const int ct = (int)(rest % n_ct);
+    const int cc = (int)((rest / n_ct) % n_cc);
+    const int tap = (int)(rest / ((int64_t)n_ct * n_cc));
+    const int co = ct * 32 + r, ci = cc * 16 + 8 * h + q;
+    const float v = (co < Cout && ci < Cin) ? w[((int64_t)co * Cin + ci) * kk + tap] * (1.f / inv_scale[co]) : 0.f;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const int64_t base = rest * 2 * 512 + h * 256 + r * 8 + q;
+    out[base] = __builtin_bit_cast(unsigned short, hi);
+    out[base + 512] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+
 }  // namespace ipdm_conv
 
 using namespace ipdm_conv;
+
+extern "C" int64_t ipdm_conv_hx2_weight_bytes(int Cout, int Cin, int k) {
+  if (Cout <= 0 || Cin <= 0 || !(k == 1 || k == 3 || k == 27)) return -1;
+  const int64_t kk = k == 27 ? 27 : k * k;
+  return kk * ((Cin + 15) / 16) * ((Cout + 31) / 32) * 2048 + (int64_t)((Cout + 31) / 32) * 32 * 4;
+}
+
+extern "C" int ipdm_conv_hx2_pack_weight(const float* w, void* packed, int Cout, int Cin, int k, void* stream) {
+  IPDM_REQUIRE(w && packed && Cout > 0 && Cin > 0 && (k == 1 || k == 3 || k == 27));
+  const int kk = k == 27 ? 27 : k * k;
+  const int n_cc = (Cin + 15) / 16, n_ct = (Cout + 31) / 32;
+  const int64_t total = (int64_t)kk * n_cc * n_ct * 512;
+  float* inv_scale = reinterpret_cast<float*>(static_cast<char*>(packed) + total * 4);
+  hipLaunchKernelGGL(hx2_scale_kernel, dim3(n_ct * 32), dim3(256), 0, ipdm_stream(stream), w, inv_scale, Cout, (long long)Cin * kk);
+  hipLaunchKernelGGL(hx2_pack_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, ipdm_stream(stream), w,
+                     (unsigned short*)packed, inv_scale, Cout, Cin, kk, n_cc, n_ct);
+  return ipdm_launch_status();
+}
 
 extern "C" int64_t ipdm_conv_bx3_weight_bytes(int Cout, int Cin, int k) {
   if (Cout <= 0 || Cin <= 0 || !(k == 1 || k == 3 || k == 27)) return -1;
@@ -529,9 +627,9 @@ extern "C" int ipdm_conv_bx3_pack_weight(const float* w, void* packed, int Cout,
   return ipdm_launch_status();
 }
 
-extern "C" int ipdm_conv3d_bx3_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
-                                   const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
-                                   int Cout, int D, int H, int W, int k, int dilation, void* stream) {
+static int conv3d_bx3_entry(const float* x, const void* wq, const float* bias, const float* coef, int act,
+                            const float* residual, float* out, float* out_act, int act_out, int B, int Cin, int Cout, int D,
+                            int H, int W, int k, int dilation, void* stream, int hx) {
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0 && (k == 1 || k == 3) && dilation >= 1);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && wq && (out || out_act) && x != out && x != out_act);
@@ -541,7 +639,21 @@ extern "C" int ipdm_conv3d_bx3_f32(const float* x, const void* wq, const float* 
   a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = k == 3 ? dilation : 1; a.act = act;
   a.D = D; a.kd = k;
   a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
+  a.hx = hx;
   return conv_bx3_dispatch(a, k, ipdm_stream(stream));
+}
+
+extern "C" int ipdm_conv3d_bx3_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
+                                   const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
+                                   int Cout, int D, int H, int W, int k, int dilation, void* stream) {
+  return conv3d_bx3_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, D, H, W, k, dilation, stream, 0);
+}
+
+/* f16x2 forms (conv_kernel.h): same arguments, wq from ipdm_conv_hx2_pack_weight */
+extern "C" int ipdm_conv3d_hx2_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
+                                   const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
+                                   int Cout, int D, int H, int W, int k, int dilation, void* stream) {
+  return conv3d_bx3_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, D, H, W, k, dilation, stream, 1);
 }
 
 extern "C" int ipdm_conv_bx3_splitk(int B, int D, int Cin, int Cout, int H, int W, int k, int dilation) {
@@ -550,10 +662,10 @@ extern "C" int ipdm_conv_bx3_splitk(int B, int D, int Cin, int Cout, int H, int 
 
 // split-K form: `work` holds ksplit * B * Cout * D * H * W floats (ksplit from ipdm_conv_bx3_splitk, > 1);
 // volume = 0: 2-D convolution (D must be 1), volume = 1: 3-D convolution with 27- / 1-tap weights
-extern "C" int ipdm_conv_bx3_splitk_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
-                                        const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
-                                        int Cout, int D, int H, int W, int k, int dilation, int volume, int ksplit,
-                                        float* work, void* stream) {
+static int conv_bx3_splitk_entry(const float* x, const void* wq, const float* bias, const float* coef, int act,
+                                 const float* residual, float* out, float* out_act, int act_out, int B, int Cin, int Cout,
+                                 int D, int H, int W, int k, int dilation, int volume, int ksplit, float* work, void* stream,
+                                 int hx) {
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0 && (k == 1 || k == 3) && dilation >= 1);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && wq && work && ksplit > 1 && (out || out_act) && x != out && x != out_act);
@@ -564,6 +676,7 @@ extern "C" int ipdm_conv_bx3_splitk_f32(const float* x, const void* wq, const fl
   a.D = D; a.kd = volume ? k : 1;             // volume: the weights carry depth taps (ipdm_conv3d_bx3_f32 semantics)
   a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = nullptr;
   a.ksplit = ksplit; a.partial = work;
+  a.hx = hx;
   int rc = conv_bx3_dispatch(a, k, ipdm_stream(stream));
   if (rc != IPDM_OK) return rc;
   const int64_t plane = (int64_t)D * H * W, total = (int64_t)B * Cout * plane;
@@ -572,9 +685,25 @@ extern "C" int ipdm_conv_bx3_splitk_f32(const float* x, const void* wq, const fl
   return ipdm_launch_status();
 }
 
-extern "C" int ipdm_conv2d_bx3_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
-                                   const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
-                                   int Cout, int H, int W, int k, int dilation, void* stream) {
+extern "C" int ipdm_conv_bx3_splitk_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
+                                        const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
+                                        int Cout, int D, int H, int W, int k, int dilation, int volume, int ksplit,
+                                        float* work, void* stream) {
+  return conv_bx3_splitk_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, D, H, W, k, dilation, volume,
+                               ksplit, work, stream, 0);
+}
+
+extern "C" int ipdm_conv_hx2_splitk_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
+                                        const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
+                                        int Cout, int D, int H, int W, int k, int dilation, int volume, int ksplit,
+                                        float* work, void* stream) {
+  return conv_bx3_splitk_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, D, H, W, k, dilation, volume,
+                               ksplit, work, stream, 1);
+}
+
+static int conv2d_bx3_entry(const float* x, const void* wq, const float* bias, const float* coef, int act,
+                            const float* residual, float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H,
+                            int W, int k, int dilation, void* stream, int hx) {
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (k == 1 || k == 3) && dilation >= 1);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && wq && (out || out_act) && x != out && x != out_act);
@@ -584,5 +713,18 @@ extern "C" int ipdm_conv2d_bx3_f32(const float* x, const void* wq, const float* 
   a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = k == 3 ? dilation : 1; a.act = act;
   a.D = 1; a.kd = 1;
   a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
+  a.hx = hx;
   return conv_bx3_dispatch(a, k, ipdm_stream(stream));
+}
+
+extern "C" int ipdm_conv2d_bx3_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
+                                   const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
+                                   int Cout, int H, int W, int k, int dilation, void* stream) {
+  return conv2d_bx3_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, H, W, k, dilation, stream, 0);
+}
+
+extern "C" int ipdm_conv2d_hx2_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
+                                   const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
+                                   int Cout, int H, int W, int k, int dilation, void* stream) {
+  return conv2d_bx3_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, H, W, k, dilation, stream, 1);
 }

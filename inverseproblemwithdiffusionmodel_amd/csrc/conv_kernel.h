@@ -25,6 +25,41 @@ __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m
   }
 }
 
+// ---- "f16x2": fp32 operands as TWO fp16 pieces, three fp16 MFMAs per product ------------------------------------------
+// v = h + l + e with h = f16(v) (round to nearest even), l = f16(v - h) (the subtraction is exact in fp32) and
+// |e| <= 2^-24 |v| while l is a normal fp16 number (|v| >~ 2^-3 / scale), |e| <= 2^-25 / scale below that: 11 + 11
+// significand bits and two signs carry what an fp32 rounding keeps.  w * x = wh*xh + (wh*xl + wl*xh) + dropped, the
+// dropped wl*xl + e-terms bounded by 3 * 2^-24 |w x| -- the size of the fp32 roundings an fp32 fma chain commits per
+// term anyway.  Three v_mfma_f32_32x32x16_f16 (fp32 accumulate, every fp16 x fp16 product exact in fp32) instead of the
+// six bf16 ones of the three-way bf16 split: half the matrix-core cycles, 4 instead of 6 bytes per weight, 2 instead of
+// 5.5 VALU per split element.  Price: fp16's exponent range.  Weights are scaled per output channel by a power of two
+// at pack time (max |w s| in [2^13, 2^14); the inverse scale rides in the blob and is applied in the epilogue's fma);
+// activations must satisfy |x| < 65504 (Winograd: the 4-term input transform |V| <= 4 max|x|, so |x| < 16376) -- an input
+// beyond that gives inf -> NaN in the output, never a silently wrong finite value; IPDM_CONV_IMPL=bx3 keeps the whole fp32
+// exponent range.  Measured against float64 on the networks' layer shapes the error is at or below the three-way bf16
+// split's and the exact-fp32 MFMA kernel's.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 values -> packed (hi, hi) and (lo, lo) fp16 pairs: v_cvt_pk_f16_f32, two v_fma_mix_f32 (v - f32(h), exact),
+// v_cvt_pk_f16_f32 -- 2 VALU per element
+__device__ __forceinline__ void split2_pk(float v0, float v1, unsigned& hp, unsigned& lp) {
+  const f16x2 hh = {(_Float16)v0, (_Float16)v1};
+  hp = __builtin_bit_cast(unsigned, hh);
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hp), "v"(v0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hp), "v"(v1));
+  const f16x2 ll = {(_Float16)r0, (_Float16)r1};
+  lp = __builtin_bit_cast(unsigned, ll);
+}
+// eight consecutive k values -> the hi and the lo MFMA operand
+__device__ __forceinline__ void split2(const float (&v)[8], uint4& h, uint4& l) {
+  split2_pk(v[0], v[1], h.x, l.x);
+  split2_pk(v[2], v[3], h.y, l.y);
+  split2_pk(v[4], v[5], h.z, l.z);
+  split2_pk(v[6], v[7], h.w, l.w);
+}
+
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{}).
 // Every register-array index below is a constant expression, so nothing is ever demoted to scratch.
 template <typename F, int... Is>
@@ -53,6 +88,8 @@ struct ConvArgs {
                              //   layers.py:291-313) to out / out_act [B][Cout][H/2][W/2]; residual is at that size too
   int ksplit = 1;            // conv_bx3 only: the K (input channel x depth tap) chunks are dealt to ksplit workgroups
   float* partial = nullptr;  //   per tile, each writing its raw partial sums to partial[ks][B][Cout][D*H*W]
+  int hx = 0;                // conv_bx3 / conv_wino_bx3: 1 = the weights are an f16x2 blob (two fp16 pieces + per-channel inverse
+                             //   scales), run the three-MFMA fp16 instantiation
   float* stats = nullptr;    // conv_wino_bx3 wide kernel (16 x 4 tile block, 16-byte DMA) only: per-plane statistics of
                              //   the RESULT as deterministic partials [B][Cout][P][3] = (count, mean, sum of squared
                              //   deviations) per (tile block, tile group), P = 2 * tiles_y * tiles_x -- what the following

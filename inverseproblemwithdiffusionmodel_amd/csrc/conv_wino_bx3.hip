@@ -72,8 +72,64 @@ __global__ __launch_bounds__(256) void wino_bx3_weight_kernel(const float* __res
   }
 }
 
-template <bool SMALL>
+// ---- f16x2 weights (conv_kernel.h): U scaled per output channel by a power of two, two fp16 pieces,
+//      [p][cc][ct][piece 2][h][r][8], followed by the inverse scales [n_ct * 32] (fp32) ----
+__device__ __forceinline__ float wino_U(const float* g, int p) {
+  const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+  const int a = p >> 2, b = p & 3;
+  float t[3];
+#pragma unroll
+  for (int jj = 0; jj < 3; ++jj) t[jj] = G[a][0] * g[jj] + G[a][1] * g[3 + jj] + G[a][2] * g[6 + jj];
+  return t[0] * G[b][0] + t[1] * G[b][1] + t[2] * G[b][2];
+}
+
+// one workgroup per output channel: inv_scale[co] = 2^-k with max |U| * 2^k in [2^13, 2^14)
+__global__ __launch_bounds__(256) void wino_hx2_scale_kernel(const float* __restrict__ w, float* __restrict__ inv_scale,
+                                                             int Cout, int Cin, int n_co_pad) {
+  __shared__ float red[256];
+  const int co = blockIdx.x;
+  float m = 0.f;
+  if (co < Cout)
+    for (int i = threadIdx.x; i < Cin * 16; i += 256) m = fmaxf(m, fabsf(wino_U(w + ((size_t)co * Cin + i / 16) * 9, i % 16)));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && co < n_co_pad) {
+    int e = 0;
+    const float mx = red[0];
+    if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &e);       // mx = f * 2^e, f in [0.5, 1)
+    inv_scale[co] = mx > 0.f && mx < INFINITY ? ldexpf(1.f, e - 14) : 1.f;   // scale 2^(14 - e): mx * scale in [2^13, 2^14)
+  }
+}
+
+__global__ __launch_bounds__(256) void wino_hx2_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                              const float* __restrict__ inv_scale, int Cout, int Cin, int n_cc,
+                                                              int n_ct) {
+  const int64_t total = (int64_t)16 * n_cc * n_ct * 512;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int q = (int)(i & 7), r = (int)((i >> 3) & 31), h = (int)((i >> 8) & 1);
+    const int64_t rest = i >> 9;
+    const int ct = (int)(rest % n_ct);
+    const int cc = (int)((rest / n_ct) % n_cc);
+    const int p = (int)(rest / ((int64_t)n_ct * n_cc));
+    const int co = ct * 32 + r, ci = cc * 16 + 8 * h + q;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) v = wino_U(w + ((size_t)co * Cin + ci) * 9, p) * (1.f / inv_scale[co]);
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const int64_t base = rest * 2 * 512 + h * 256 + r * 8 + q;
+    out[base] = __builtin_bit_cast(unsigned short, hi);
+    out[base + 512] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+
+template <bool HX, bool SMALL>
 __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
+  constexpr int NPC = HX ? 2 : 3;                            // operand pieces; FRAG: 16-byte units per (chunk, channel tile)
+  constexpr int FRAG = 64 * NPC;
   extern __shared__ __align__(16) float lds[];
   unsigned long long t0 = 0, t1 = 0, t2 = 0;
   if (a.dbg) t0 = __builtin_amdgcn_s_memtime();
@@ -158,6 +214,23 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
       tmp[2 * 4 + c] = dd[2 * 4 + c] - dd[1 * 4 + c];
       tmp[3 * 4 + c] = dd[1 * 4 + c] - dd[3 * 4 + c];
     }
+    if constexpr (HX) {
+      // f16x2 stage: Vs[pos][piece 2][channel pair 8][tile 64] 32-bit words, channel 2c in the low half of a word: the
+      // reader's four words per piece ARE its MFMA operand.  This kernel stages one channel at a time: 16-bit stores.
+      _Float16* vs = reinterpret_cast<_Float16*>(st) + ((kc >> 1) * X_TILES + mytile) * 2 + (kc & 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v4[4] = {tmp[r * 4 + 0] - tmp[r * 4 + 2], tmp[r * 4 + 1] + tmp[r * 4 + 2], tmp[r * 4 + 2] - tmp[r * 4 + 1],
+                             tmp[r * 4 + 1] - tmp[r * 4 + 3]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const _Float16 hi = (_Float16)v4[c];
+          const _Float16 lo = (_Float16)(v4[c] - (float)hi);
+          vs[((r * 4 + c) * 2 + 0) * (X_KC * X_TILES)] = hi;
+          vs[((r * 4 + c) * 2 + 1) * (X_KC * X_TILES)] = lo;
+        }
+      }
+    } else {
     float* vs = st + kc * X_TILES + mytile;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -165,6 +238,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
       vs[(r * 4 + 1) * X_KC * X_TILES] = tmp[r * 4 + 1] + tmp[r * 4 + 2];
       vs[(r * 4 + 2) * X_KC * X_TILES] = tmp[r * 4 + 2] - tmp[r * 4 + 1];
       vs[(r * 4 + 3) * X_KC * X_TILES] = tmp[r * 4 + 1] - tmp[r * 4 + 3];
+    }
     }
   };
 
@@ -205,14 +279,14 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
 
   // ---- A fragments ----
   const uint4* wq = reinterpret_cast<const uint4*>(a.wt);
-  const size_t pos_stride = (size_t)n_cc * n_ct * 192;
-  const int a_lane = (co_tile * 2) * 192 + lane;             // channel tile c adds 192
-  auto load_A = [&](bf16x8 (&fr)[2][3], int p, int cc) {
-    const uint4* base = wq + (size_t)p * pos_stride + (size_t)cc * n_ct * 192 + a_lane;
+  const size_t pos_stride = (size_t)n_cc * n_ct * FRAG;
+  const int a_lane = (co_tile * 2) * FRAG + lane;            // channel tile c adds FRAG
+  auto load_A = [&](uint4 (&fr)[2][NPC], int p, int cc) {
+    const uint4* base = wq + (size_t)p * pos_stride + (size_t)cc * n_ct * FRAG + a_lane;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) fr[c][s] = __builtin_bit_cast(bf16x8, base[c * 192 + s * 64]);
+      for (int s = 0; s < NPC; ++s) fr[c][s] = base[c * FRAG + s * 64];
   };
   // ---- B operand: 8 channels (8h .. 8h+7) of tile (tg*32 + j) at position p, fp32 ----
   const int b_lane = (8 * h) * X_TILES + j;
@@ -221,6 +295,13 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) raw[q] = bp[q * X_TILES];
   };
+  // f16x2: channel pairs 4h .. 4h+3 of both pieces -- the operand itself, no split
+  auto load_Bh = [&](uint4 (&fr)[2], const float* cur, int pi, int tg) {
+    const unsigned* bp = reinterpret_cast<const unsigned*>(cur) + (p0 + pi) * (X_KC * X_TILES) + (4 * h) * X_TILES + tg * 32 + j;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      fr[s] = make_uint4(bp[s * 8 * X_TILES], bp[(s * 8 + 1) * X_TILES], bp[(s * 8 + 2) * X_TILES], bp[(s * 8 + 3) * X_TILES]);
+  };
 
   f32x16 acc[2][2][2];                                       // [position][channel tile][tile group]
 #pragma unroll
@@ -228,7 +309,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i >> 2][(i >> 1) & 1][i & 1][r] = 0.f;
 
-  bf16x8 afr[2][2][3];
+  uint4 afr[2][2][NPC];
   const int n_chunks = n_cc;
   // prologue: stage 0 completely, and channel 2w of chunk 1 already in flight in dreg
   load_A(afr[0], p0, 0);
@@ -268,14 +349,22 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
     const int ch1 = ch + 1 < n_chunks ? ch + 1 : n_chunks - 1;
     const int ch2 = ch + 2 < n_chunks ? ch + 2 : n_chunks - 1;
     bf16x8 bs[2][3];
+    uint4 bsh[2][2];
     float raw[8];
-    load_B(raw, cur, 0, 0);
-    split3(raw, bs[0][0], bs[0][1], bs[0][2]);
+    if constexpr (HX) {
+      load_Bh(bsh[0], cur, 0, 0);
+    } else {
+      load_B(raw, cur, 0, 0);
+      split3(raw, bs[0][0], bs[0][1], bs[0][2]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     static_for<4>([&](auto sc) {
       constexpr int st = decltype(sc)::value;
       constexpr int pi = st >> 1, tg = st & 1;
-      if constexpr (st < 3) load_B(raw, cur, (st + 1) >> 1, (st + 1) & 1);
+      if constexpr (st < 3) {
+        if constexpr (HX) load_Bh(bsh[(st + 1) & 1], cur, (st + 1) >> 1, (st + 1) & 1);
+        else load_B(raw, cur, (st + 1) >> 1, (st + 1) & 1);
+      }
       if constexpr (SMALL) {
         if constexpr (st == 0) {
           store_patch(nxt, 2 * wave);
@@ -300,22 +389,42 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
         if constexpr (st == 1) issue_dma(ch2);
         if constexpr (st == 2) load_A(afr[0], p0, ch1);
       }
+      constexpr bool XFORM = SMALL ? (st == 0 || st == 2) : st == 0;
+      constexpr bool VMEM = SMALL ? (st == 0 || st == 2) : st < 3;
+      if constexpr (HX) {
+        const f16x8 bh = __builtin_bit_cast(f16x8, bsh[st & 1][0]), bl = __builtin_bit_cast(f16x8, bsh[st & 1][1]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          f32x16 v = acc[pi][c][tg];
+          v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][1]), bh, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][0]), bl, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][0]), bh, v, 0, 0, 0);
+          acc[pi][c][tg] = v;
+        }
+        if constexpr (st < 3) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);        // next step's LDS reads first
+        if constexpr (!SMALL && XFORM) __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, XFORM ? (SMALL ? 20 : 40) : 3, 0);
+          if constexpr (XFORM) __builtin_amdgcn_sched_group_barrier(0x200, SMALL ? 6 : 11, 0);
+          if constexpr (VMEM) __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+        }
+      } else {
       if constexpr (st < 3) split3(raw, bs[(st + 1) & 1][0], bs[(st + 1) & 1][1], bs[(st + 1) & 1][2]);
       const bf16x8 bh = bs[st & 1][0], bm = bs[st & 1][1], bl = bs[st & 1][2];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         f32x16 v = acc[pi][c][tg];
-        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][2], bh, v, 0, 0, 0);
-        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bl, v, 0, 0, 0);
-        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][1], bm, v, 0, 0, 0);
-        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][1], bh, v, 0, 0, 0);
-        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bm, v, 0, 0, 0);
-        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bh, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[pi][c][2]), bh, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[pi][c][0]), bl, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[pi][c][1]), bm, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[pi][c][1]), bh, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[pi][c][0]), bm, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[pi][c][0]), bh, v, 0, 0, 0);
         acc[pi][c][tg] = v;
       }
       if constexpr (st < 3) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);          // next step's LDS reads first
-      constexpr bool XFORM = SMALL ? (st == 0 || st == 2) : st == 0;
-      constexpr bool VMEM = SMALL ? (st == 0 || st == 2) : st < 3;
       if constexpr (!SMALL && XFORM) __builtin_amdgcn_sched_group_barrier(0x100, 16, 0); // the patch reads
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
@@ -323,6 +432,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x006, XFORM ? (SMALL ? 10 : 12) : 5, 0);  // VALU / SALU in its shadow
         if constexpr (XFORM) __builtin_amdgcn_sched_group_barrier(0x200, SMALL ? 2 : 3, 0);   // patch stores
         if constexpr (VMEM) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);          // patch / fragment loads, DMA
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!SMALL && st == 0) __syncthreads();        // everyone has read the raw stage
@@ -349,7 +459,8 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
   const float* const bias_p = has_bias ? a.bias : a.wt;
   const bool res_ok = has_res && out_ok;
   const int rd = res_ok ? d : 0;
-  float bv[2][4];
+  const float* const scale_p = HX ? reinterpret_cast<const float*>(wq + 16 * pos_stride) : a.wt;   // f16x2: inverse scales
+  float bv[2][4], sv[2][4];
   float2 rv[2][4][2];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -357,6 +468,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int co = co0 + c * 32 + cg * 4 + i;
       bv[c][i] = bias_p[has_bias ? co : 0];
+      sv[c][i] = scale_p[HX ? co : 0];
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) {
         const size_t o = res_ok ? ((size_t)b * a.Cout + co) * HW + (size_t)(oy + (SMALL ? d * ii : ii)) * a.W + ox : 0;
@@ -379,7 +491,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                            // the one counted wait for this round's loads sits here
-      asm volatile("" : "+v"(bv[c][i]));
+      asm volatile("" : "+v"(bv[c][i]), "+v"(sv[c][i]));
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) asm volatile("" : "+v"(rv[c][i][ii].x), "+v"(rv[c][i][ii].y));
     }
@@ -400,8 +512,14 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
         const float bias = has_bias ? bv[c][i] : 0.f;
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
-          float y0v = tt[ii][0] + tt[ii][1] + tt[ii][2] + bias;
-          float y1v = tt[ii][1] - tt[ii][2] - tt[ii][3] + bias;
+          float y0v = tt[ii][0] + tt[ii][1] + tt[ii][2], y1v = tt[ii][1] - tt[ii][2] - tt[ii][3];
+          if constexpr (HX) {
+            y0v = __builtin_fmaf(y0v, sv[c][i], bias);
+            y1v = __builtin_fmaf(y1v, sv[c][i], bias);
+          } else {
+            y0v += bias;
+            y1v += bias;
+          }
           const size_t o = ((size_t)b * a.Cout + co) * HW + (size_t)(oy + (SMALL ? d * ii : ii)) * a.W + ox;
           if (has_res) {
             y0v += rv[c][i][ii].x;
@@ -478,8 +596,10 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // 26 16-byte LDS-DMA pieces per chunk whose out-of-image quads the range check zeroes; a thread gathers its 4 x 4 patch
 // from there (16 LDS reads) instead of 16 scattered 4-byte global loads per patch -- the address path was what held the
 // register-staged kernel at 12.7 k cycles per chunk on dilation-2 layers.
-template <int TX, int TY, bool CO_MAJOR, bool DMA4, bool POOL = false, bool STATS = false, bool KSP = false, bool POLY = false>
+template <bool HX, int TX, int TY, bool CO_MAJOR, bool DMA4, bool POOL = false, bool STATS = false, bool KSP = false, bool POLY = false>
 __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int total_tiles) {
+  constexpr int NPC = HX ? 2 : 3;                            // operand pieces; FRAG: 16-byte units per (chunk, channel tile)
+  constexpr int FRAG = 64 * NPC;
   static_assert(!POLY || (TX == 8 && TY == 8 && DMA4 && !POOL && !STATS && !KSP), "POLY: the 8 x 8 form, plain epilogue");
   constexpr int PPW = 24, PPH = 17;                           // POLY: padded row pitch / rows per channel
   constexpr int QC = POLY ? PPW / 4 : TX / 2 + 2, RC4 = 4 * QC;   // quads / floats per raw row (x0-4 .. x0+2TX+3)
@@ -674,20 +794,74 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     }
   };
 
+  // f16x2: B^T d B of the patch in dreg -> v (registers); the two channels 2w, 2w+1 of a tile are then split together and
+  // stored as packed fp16 pairs, Vs[pos][piece 2][channel pair 8][tile 64] 32-bit words (channel 2c in the low half): the
+  // reader's four words per piece ARE its MFMA operand -- the split is done once, by the writer, at 2 VALU per element
+  auto transform = [&](float (&v)[16]) {
+    const float(&dd)[16] = dreg;
+    float tmp[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      tmp[0 * 4 + c] = dd[0 * 4 + c] - dd[2 * 4 + c];
+      tmp[1 * 4 + c] = dd[1 * 4 + c] + dd[2 * 4 + c];
+      tmp[2 * 4 + c] = dd[2 * 4 + c] - dd[1 * 4 + c];
+      tmp[3 * 4 + c] = dd[1 * 4 + c] - dd[3 * 4 + c];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      v[rr * 4 + 0] = tmp[rr * 4 + 0] - tmp[rr * 4 + 2];
+      v[rr * 4 + 1] = tmp[rr * 4 + 1] + tmp[rr * 4 + 2];
+      v[rr * 4 + 2] = tmp[rr * 4 + 2] - tmp[rr * 4 + 1];
+      v[rr * 4 + 3] = tmp[rr * 4 + 1] - tmp[rr * 4 + 3];
+    }
+  };
+  auto store_pair = [&](float* st, const float (&va)[16], const float (&vb)[16]) {
+    unsigned* vs = reinterpret_cast<unsigned*>(st) + wave * X_TILES + mytile;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      unsigned hp, lp;
+      split2_pk(va[p], vb[p], hp, lp);
+      vs[(p * 2 + 0) * (8 * X_TILES)] = hp;
+      vs[(p * 2 + 1) * (8 * X_TILES)] = lp;
+    }
+  };
+  // stage the chunk held in the raw stage into V stage `st` (this thread: its tile, channels 2w and 2w+1)
+  auto stage_chunk = [&](float* st) {
+    if constexpr (HX) {
+      float va[16], vb[16];
+      read_patch(2 * wave);
+      transform(va);
+      read_patch(2 * wave + 1);
+      transform(vb);
+      store_pair(st, va, vb);
+    } else {
+      read_patch(2 * wave);
+      store_patch(st, 2 * wave);
+      read_patch(2 * wave + 1);
+      store_patch(st, 2 * wave + 1);
+    }
+  };
+
   const uint4* wq = reinterpret_cast<const uint4*>(a.wt);
-  const size_t pos_stride = (size_t)n_cc * n_ct * 192;
-  auto load_A = [&](bf16x8 (&fr)[2][3], int p, int cc, int co_tile) {
-    const uint4* base = wq + (size_t)p * pos_stride + ((size_t)cc * n_ct + co_tile * 2) * 192 + lane;
+  const size_t pos_stride = (size_t)n_cc * n_ct * FRAG;
+  auto load_A = [&](uint4 (&fr)[2][NPC], int p, int cc, int co_tile) {
+    const uint4* base = wq + (size_t)p * pos_stride + ((size_t)cc * n_ct + co_tile * 2) * FRAG + lane;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) fr[c][s] = __builtin_bit_cast(bf16x8, base[c * 192 + s * 64]);
+      for (int s = 0; s < NPC; ++s) fr[c][s] = base[c * FRAG + s * 64];
   };
   const int b_lane = (8 * h) * X_TILES + j;
   auto load_B = [&](float (&raw)[8], const float* cur, int pi, int tg) {
     const float* bp = cur + (p0 + pi) * (X_KC * X_TILES) + tg * 32 + b_lane;
 #pragma unroll
     for (int qq = 0; qq < 8; ++qq) raw[qq] = bp[qq * X_TILES];
+  };
+  auto load_Bh = [&](uint4 (&fr)[2], const float* cur, int pi, int tg) {      // f16x2: the operand itself, no split
+    const unsigned* bp = reinterpret_cast<const unsigned*>(cur) + (p0 + pi) * (X_KC * X_TILES) + (4 * h) * X_TILES + tg * 32 + j;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      fr[s] = make_uint4(bp[s * 8 * X_TILES], bp[(s * 8 + 1) * X_TILES], bp[(s * 8 + 2) * X_TILES], bp[(s * 8 + 3) * X_TILES]);
   };
 
   f32x16 acc[2][2][2];
@@ -701,16 +875,13 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
 
   // ---- prologue of the first tile ----
   Geo cur_g = geo_of(tile);
-  bf16x8 afr[2][2][3];
+  uint4 afr[2][2][NPC];
   load_A(afr[0], p0, cur_g.c0, cur_g.co_tile);
   set_dma_geo(cur_g);
   issue_dma(0);
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  read_patch(2 * wave);
-  store_patch(lds, 2 * wave);
-  read_patch(2 * wave + 1);
-  store_patch(lds, 2 * wave + 1);
+  stage_chunk(lds);
   __syncthreads();
   issue_dma(1);
   __builtin_amdgcn_s_waitcnt(0);
@@ -743,41 +914,66 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       const int a_chunk = a_next ? next_g.c0 : cur_g.c0 + ch + 1;
       const int a_cot = a_next ? next_g.co_tile : cur_g.co_tile;
       bf16x8 bs[2][3];
+      uint4 bsh[2][2];
       float raw[8];
-      load_B(raw, cur, 0, 0);
-      split3(raw, bs[0][0], bs[0][1], bs[0][2]);
+      if constexpr (HX) {
+        load_Bh(bsh[0], cur, 0, 0);
+      } else {
+        load_B(raw, cur, 0, 0);
+        split3(raw, bs[0][0], bs[0][1], bs[0][2]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       static_for<4>([&](auto sc) {
         constexpr int st = decltype(sc)::value;
         constexpr int pi = st >> 1, tg = st & 1;
-        if constexpr (st < 3) load_B(raw, cur, (st + 1) >> 1, (st + 1) & 1);
+        if constexpr (st < 3) {
+          if constexpr (HX) load_Bh(bsh[(st + 1) & 1], cur, (st + 1) >> 1, (st + 1) & 1);
+          else load_B(raw, cur, (st + 1) >> 1, (st + 1) & 1);
+        }
         if constexpr (st == 0) {
-          read_patch(2 * wave);
-          store_patch(nxt, 2 * wave);
-          read_patch(2 * wave + 1);
-          store_patch(nxt, 2 * wave + 1);
+          stage_chunk(nxt);
           load_A(afr[1], p0 + 1, cur_g.c0 + ch, cur_g.co_tile);
         }
         if constexpr (st == 1) issue_dma(dma_chunk);
         if constexpr (st == 2) load_A(afr[0], p0, a_chunk, a_cot);
+        constexpr bool XFORM = st == 0;
+        constexpr int MIDSTEP = 0;                                  // the mid-chunk barrier follows step 0
+        if constexpr (HX) {
+          const f16x8 bh = __builtin_bit_cast(f16x8, bsh[st & 1][0]), bl = __builtin_bit_cast(f16x8, bsh[st & 1][1]);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            f32x16 v = acc[pi][c][tg];
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][1]), bh, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][0]), bl, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][0]), bh, v, 0, 0, 0);
+            acc[pi][c][tg] = v;
+          }
+          constexpr int XRD = 16, XVALU = 28, XST = 6;              // patch reads, then per MFMA: VALU, packed-pair stores
+          if constexpr (st < 3) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+          if constexpr (XFORM) __builtin_amdgcn_sched_group_barrier(0x100, XRD, 0);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, XFORM ? XVALU : 3, 0);
+            if constexpr (XFORM) __builtin_amdgcn_sched_group_barrier(0x200, XST, 0);
+            if constexpr (st < 3) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+          }
+        } else {
         if constexpr (st < 3) split3(raw, bs[(st + 1) & 1][0], bs[(st + 1) & 1][1], bs[(st + 1) & 1][2]);
         const bf16x8 bh = bs[st & 1][0], bm = bs[st & 1][1], bl = bs[st & 1][2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           f32x16 v = acc[pi][c][tg];
-#ifndef IPDM_PROBE_HALF_MFMA
-          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][2], bh, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bl, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][1], bm, v, 0, 0, 0);
-#endif
-          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][1], bh, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bm, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[pi][c][0], bh, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[pi][c][2]), bh, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[pi][c][0]), bl, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[pi][c][1]), bm, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[pi][c][1]), bh, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[pi][c][0]), bm, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[pi][c][0]), bh, v, 0, 0, 0);
           acc[pi][c][tg] = v;
         }
         if constexpr (st < 3) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        constexpr bool XFORM = st == 0;
-        constexpr int XRD = 16, XVALU = 12, XST = 3, MIDSTEP = 0;   // patch reads, VALU per MFMA, patch stores; barrier after step 0
+        constexpr int XRD = 16, XVALU = 12, XST = 3;                // patch reads, VALU per MFMA, patch stores
         if constexpr (XFORM) __builtin_amdgcn_sched_group_barrier(0x100, XRD, 0);
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
@@ -785,6 +981,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
           __builtin_amdgcn_sched_group_barrier(0x006, XFORM ? XVALU : 5, 0);
           if constexpr (XFORM) __builtin_amdgcn_sched_group_barrier(0x200, XST, 0);
           if constexpr (st < 3) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
         IPDM_TR(1 + st);
@@ -812,6 +1009,8 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     constexpr bool AHEAD = TX == 16;
     float2 resv[AHEAD ? 2 : 1][2][NR];
     float biasv[AHEAD ? 2 : 1][2];
+    [[maybe_unused]] float scalev[AHEAD ? 2 : 1][2];            // f16x2: the channel's inverse weight scale (blob tail)
+    const float* const scale_p = HX ? reinterpret_cast<const float*>(wq + 16 * pos_stride) : a.wt;
     auto out_index = [&](int c, int tg, int i, int ii) -> size_t {
       if constexpr (POLY) {                                     // -> the first of the row's two outputs; the second: + d
         int py, px;
@@ -842,6 +1041,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         biasv[bf][i] = bias_p[has_bias ? co0 + c * 32 + ecg * 2 + i : 0];
+        if constexpr (HX) scalev[bf][i] = scale_p[co0 + c * 32 + ecg * 2 + i];
 #pragma unroll
         for (int ii = 0; ii < NR; ++ii) {
           const size_t o = res_ok ? out_index(c, tg, i, ii) : 0;
@@ -890,8 +1090,15 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
           if constexpr (POOL) {
             // ConvMeanPool: (y[::2,::2] + y[1::2,::2] + y[::2,1::2] + y[1::2,1::2]) / 4 in the reference's order; the
             // output tile IS the 2x2 pooling window, so the full-resolution result is never written
-            const float y00 = tt[0][0] + tt[0][1] + tt[0][2] + bias, y01 = tt[0][1] - tt[0][2] - tt[0][3] + bias;
-            const float y10 = tt[1][0] + tt[1][1] + tt[1][2] + bias, y11 = tt[1][1] - tt[1][2] - tt[1][3] + bias;
+            float y00 = tt[0][0] + tt[0][1] + tt[0][2], y01 = tt[0][1] - tt[0][2] - tt[0][3];
+            float y10 = tt[1][0] + tt[1][1] + tt[1][2], y11 = tt[1][1] - tt[1][2] - tt[1][3];
+            if constexpr (HX) {
+              const float sc = scalev[bf][i];
+              y00 = __builtin_fmaf(y00, sc, bias); y01 = __builtin_fmaf(y01, sc, bias);
+              y10 = __builtin_fmaf(y10, sc, bias); y11 = __builtin_fmaf(y11, sc, bias);
+            } else {
+              y00 += bias; y01 += bias; y10 += bias; y11 += bias;
+            }
             float v = (((y00 + y10) + y01) + y11) * 0.25f;
             const size_t o = out_index(c, tg, i, 0);
             if (has_res) v += resv[bf][i][0].x;
@@ -901,8 +1108,14 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
           } else {
 #pragma unroll
           for (int ii = 0; ii < 2; ++ii) {
-            float y0v = tt[ii][0] + tt[ii][1] + tt[ii][2] + bias;
-            float y1v = tt[ii][1] - tt[ii][2] - tt[ii][3] + bias;
+            float y0v = tt[ii][0] + tt[ii][1] + tt[ii][2], y1v = tt[ii][1] - tt[ii][2] - tt[ii][3];
+            if constexpr (HX) {
+              y0v = __builtin_fmaf(y0v, scalev[bf][i], bias);
+              y1v = __builtin_fmaf(y1v, scalev[bf][i], bias);
+            } else {
+              y0v += bias;
+              y1v += bias;
+            }
             const size_t o = out_index(c, tg, i, ii);
             if (has_res) {
               y0v += resv[bf][i][ii].x;
@@ -995,332 +1208,6 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
 #undef IPDM_TR
 
 
-// ---- 128 output channels x 32 tiles per workgroup (Cout % 128 == 0) -------------------------------------------------
-// Same persistent scheme, different split of the 128 accumulator registers: a wave still owns two positions, but
-// for FOUR channel tiles (128 channels) of ONE 32-tile group.  Every split V fragment now feeds 24 MFMAs instead of 12,
-// so the operand split -- the bulk of the VALU work that made the 64x64 form issue-bound -- halves per MFMA, the
-// transform / LDS / DMA work per MFMA halves too (32 tiles per 128 channels), and the input region is fetched once
-// instead of once per 64-channel tile.  The price is the A side: 24 instead of 12 one-KiB fragment loads per wave
-// and chunk (L2 -> CU at about half of its rate).  LDS: two 32 KiB V stages, a 16 KiB raw stage and a separate 64 KiB
-// exchange buffer for the epilogue (four rounds, one channel tile each), 144 KiB.
-// Activations are streamed (each byte read or written once per launch) while the Winograd weights are re-read by every
-// workgroup: the input DMA, the residual loads and the output stores carry the non-temporal policy so that they do
-// not push the weights out of L2.  -DIPDM_NO_NT builds the default-policy variant (A/B).
-#ifdef IPDM_NO_NT
-#define IPDM_NT_AUX 0
-#define IPDM_NT_LOAD2(p) (*reinterpret_cast<const float2*>(p))
-#define IPDM_NT_STORE2(p, x, y) (*reinterpret_cast<float2*>(p) = make_float2((x), (y)))
-#else
-#define IPDM_NT_AUX 2
-typedef float ipdm_f2v __attribute__((ext_vector_type(2)));
-#define IPDM_NT_LOAD2(p) ([&] { const ipdm_f2v t_ = __builtin_nontemporal_load(reinterpret_cast<const ipdm_f2v*>(p)); return make_float2(t_.x, t_.y); }())
-#define IPDM_NT_STORE2(p, x, y) __builtin_nontemporal_store(ipdm_f2v{(x), (y)}, reinterpret_cast<ipdm_f2v*>(p))
-#endif
-constexpr int Y_TILES = 32;
-constexpr int Y_V_ELEMS = 16 * X_KC * Y_TILES;                 // 8192 floats per stage
-constexpr int Y_RCH = 256;                                     // raw floats per channel (4 wave-instructions)
-constexpr int Y_R_ELEMS = X_KC * Y_RCH;
-constexpr int Y_M_ELEMS = 16 * 32 * Y_TILES;                   // 16384 floats
-constexpr size_t Y_LDS_BYTES = (2 * (size_t)Y_V_ELEMS + Y_R_ELEMS + Y_M_ELEMS) * sizeof(float);
-
-template <int TX, int TY, bool CO_MAJOR>
-__global__ __launch_bounds__(512) void conv_wino_bx3_c128_kernel(ConvArgs a, int total_tiles) {
-  static_assert(TX * TY == Y_TILES, "32 tiles per workgroup");
-  constexpr int RC = 2 * TX + 2, RR = 2 * TY + 2;             // raw region: 34 x 6 (wide) or 18 x 10 (16-pixel images)
-  static_assert(RC * RR <= Y_RCH, "raw region fits its LDS slot");
-  extern __shared__ __align__(16) float lds[];
-  unsigned long long t0 = 0, t1 = 0, t2 = 0;
-  if (a.dbg) t0 = __builtin_amdgcn_s_memtime();
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, j = lane & 31;
-  const int HW = a.H * a.W;
-  const int n_cc = a.Cin / X_KC, n_ct = a.Cout / 32;
-  const int n_chunks = n_cc;                                  // >= 2 (launcher)
-  const int p0 = 2 * wave;
-  const int co_tiles = a.Cout / 128;
-
-  const int S = gridDim.x / 8;
-  const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
-  const int q = total_tiles / 8, r8 = total_tiles % 8;
-  const int x_start = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
-  const int x_end = x_start + q + (xcd < r8 ? 1 : 0);
-  int tile = x_start + slot;
-  if (tile >= x_end) return;
-
-  struct Geo { int b, y0, x0, co_tile; };
-  auto geo_of = [&](int L) {
-    Geo g;
-    const int n_px = total_tiles / co_tiles;
-    g.co_tile = CO_MAJOR ? L / n_px : L % co_tiles;
-    int t = CO_MAJOR ? L % n_px : L / co_tiles;
-    const int tx = t % a.tiles_x;
-    t /= a.tiles_x;
-    g.y0 = (t % a.tiles_y) * (2 * TY);
-    g.x0 = tx * (2 * TX);
-    g.b = t / a.tiles_y;
-    return g;
-  };
-
-  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x), 0, (int)((size_t)a.B * a.Cin * HW * 4), 0x00020000);
-  float* const rs = lds + 2 * Y_V_ELEMS;
-  float* const ms = rs + Y_R_ELEMS;                           // M[pos 16][co 32][tile 32]
-
-  // raw stage by LDS-DMA: wave w brings in channels 2w, 2w+1 (4 x 64 floats each)
-  int dma_off[4];
-  int dma_b = 0;
-  auto set_dma_geo = [&](const Geo& g) {
-    dma_b = g.b;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int e = k * 64 + lane;
-      const int rr = e / RC, c = e - rr * RC;
-      const int gy = g.y0 - 1 + rr, gx = g.x0 - 1 + c;
-      const bool ok = e < RR * RC && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      dma_off[k] = ok ? (gy * a.W + gx) * 4 : 0x40000000;
-    }
-  };
-  auto issue_dma = [&](int chunk) {
-#pragma unroll
-    for (int cl = 0; cl < 2; ++cl) {
-      const int kc = 2 * wave + cl;
-      const int soff = (int)(((size_t)dma_b * a.Cin + chunk * X_KC + kc) * HW * 4);
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(rs + kc * Y_RCH + k * 64), 4,
-                                                 dma_off[k], soff, 0, IPDM_NT_AUX);
-    }
-  };
-  // staging: this thread transforms tile `mytile` of channel `mykc` = 2w + (lane >> 5) of every chunk
-  const int mytile = lane & 31, mykc = 2 * wave + (lane >> 5);
-  float dreg[16];
-  const int r_lane = mykc * Y_RCH + (2 * (mytile / TX)) * RC + 2 * (mytile % TX);
-  auto read_patch = [&]() {
-    const float* rp = rs + r_lane;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const float2 lo = *reinterpret_cast<const float2*>(rp + rr * RC);
-      const float2 hi = *reinterpret_cast<const float2*>(rp + rr * RC + 2);
-      dreg[rr * 4 + 0] = lo.x; dreg[rr * 4 + 1] = lo.y; dreg[rr * 4 + 2] = hi.x; dreg[rr * 4 + 3] = hi.y;
-    }
-  };
-  auto store_patch = [&](float* st) {                         // Vs[pos][kc 16][tile 32]
-    const float(&dd)[16] = dreg;
-    float tmp[16];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      tmp[0 * 4 + c] = dd[0 * 4 + c] - dd[2 * 4 + c];
-      tmp[1 * 4 + c] = dd[1 * 4 + c] + dd[2 * 4 + c];
-      tmp[2 * 4 + c] = dd[2 * 4 + c] - dd[1 * 4 + c];
-      tmp[3 * 4 + c] = dd[1 * 4 + c] - dd[3 * 4 + c];
-    }
-    float* vs = st + mykc * Y_TILES + mytile;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      vs[(rr * 4 + 0) * X_KC * Y_TILES] = tmp[rr * 4 + 0] - tmp[rr * 4 + 2];
-      vs[(rr * 4 + 1) * X_KC * Y_TILES] = tmp[rr * 4 + 1] + tmp[rr * 4 + 2];
-      vs[(rr * 4 + 2) * X_KC * Y_TILES] = tmp[rr * 4 + 2] - tmp[rr * 4 + 1];
-      vs[(rr * 4 + 3) * X_KC * Y_TILES] = tmp[rr * 4 + 1] - tmp[rr * 4 + 3];
-    }
-  };
-
-  // A fragments of (position p, chunk cc, channel tiles 4*co_tile + 2*cp, +1)
-  const uint4* wq = reinterpret_cast<const uint4*>(a.wt);
-  const size_t pos_stride = (size_t)n_cc * n_ct * 192;
-  auto load_A = [&](bf16x8 (&fr)[2][3], int p, int cc, int co_tile, int cp) {
-    const uint4* base = wq + (size_t)p * pos_stride + ((size_t)cc * n_ct + co_tile * 4 + cp * 2) * 192 + lane;
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int s = 0; s < 3; ++s) fr[c][s] = __builtin_bit_cast(bf16x8, base[c * 192 + s * 64]);
-  };
-  const int b_lane = (8 * h) * Y_TILES + j;
-  auto load_B = [&](float (&raw)[8], const float* cur, int pi) {
-    const float* bp = cur + (p0 + pi) * (X_KC * Y_TILES) + b_lane;
-#pragma unroll
-    for (int qq = 0; qq < 8; ++qq) raw[qq] = bp[qq * Y_TILES];
-  };
-
-  f32x16 acc[2][4];                                           // [position][channel tile]
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) acc[i >> 2][i & 3][rr] = 0.f;
-  };
-  zero_acc();
-
-  // ---- prologue of the first tile ----
-  Geo cur_g = geo_of(tile);
-  bf16x8 afr[2][2][3];
-  load_A(afr[0], p0, 0, cur_g.co_tile, 0);
-  set_dma_geo(cur_g);
-  issue_dma(0);
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  read_patch();
-  store_patch(lds);
-  __syncthreads();
-  issue_dma(1);
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (a.dbg) t1 = __builtin_amdgcn_s_memtime();
-
-  int g = 0;
-  while (true) {
-    const int next_tile = tile + S;
-    const bool has_next = next_tile < x_end;
-    const Geo next_g = geo_of(has_next ? next_tile : tile);
-    for (int ch = 0; ch < n_chunks; ++ch, ++g) {
-      const float* cur = lds + (g & 1) * Y_V_ELEMS;
-      float* nxt = lds + ((g + 1) & 1) * Y_V_ELEMS;
-      const bool dma_next = ch + 2 >= n_chunks;
-      const int dma_chunk = dma_next ? ch + 2 - n_chunks : ch + 2;
-      if (ch + 2 == n_chunks) set_dma_geo(next_g);
-      const bool a_next = ch + 1 >= n_chunks;
-      const int a_chunk = a_next ? 0 : ch + 1;
-      const int a_cot = a_next ? next_g.co_tile : cur_g.co_tile;
-      bf16x8 bs[2][3];
-      float raw[8];
-      load_B(raw, cur, 0);
-#if defined(IPDM_PROBE) && (IPDM_PROBE & 1)
-      { uint4 u0 = make_uint4(__float_as_uint(raw[0]), __float_as_uint(raw[1]), __float_as_uint(raw[2]), __float_as_uint(raw[3]));
-        uint4 u1 = make_uint4(__float_as_uint(raw[4]), __float_as_uint(raw[5]), __float_as_uint(raw[6]), __float_as_uint(raw[7]));
-        bs[0][0] = __builtin_bit_cast(bf16x8, u0); bs[0][1] = __builtin_bit_cast(bf16x8, u1); bs[0][2] = bs[0][0]; }
-#else
-      split3(raw, bs[0][0], bs[0][1], bs[0][2]);
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      // four steps (position pi, channel-tile pair cp) of 12 MFMAs; A fragments one step ahead
-      static_for<4>([&](auto sc) {
-        constexpr int st = decltype(sc)::value;
-        constexpr int pi = st >> 1, cp = st & 1;
-        if constexpr (st == 0) {
-#if !(defined(IPDM_PROBE) && (IPDM_PROBE & 8))
-          load_A(afr[1], p0, ch, cur_g.co_tile, 1);
-#endif
-#if !(defined(IPDM_PROBE) && (IPDM_PROBE & 2))
-          read_patch();
-          store_patch(nxt);
-#endif
-        }
-        if constexpr (st == 1) {
-#if !(defined(IPDM_PROBE) && (IPDM_PROBE & 8))
-          load_A(afr[0], p0 + 1, ch, cur_g.co_tile, 0);
-#endif
-#if !(defined(IPDM_PROBE) && (IPDM_PROBE & 4))
-          issue_dma(dma_chunk);
-#endif
-          load_B(raw, cur, 1);
-#if defined(IPDM_PROBE) && (IPDM_PROBE & 1)
-          { uint4 u0 = make_uint4(__float_as_uint(raw[0]), __float_as_uint(raw[1]), __float_as_uint(raw[2]), __float_as_uint(raw[3]));
-            uint4 u1 = make_uint4(__float_as_uint(raw[4]), __float_as_uint(raw[5]), __float_as_uint(raw[6]), __float_as_uint(raw[7]));
-            bs[1][0] = __builtin_bit_cast(bf16x8, u0); bs[1][1] = __builtin_bit_cast(bf16x8, u1); bs[1][2] = bs[1][0]; }
-#else
-          split3(raw, bs[1][0], bs[1][1], bs[1][2]);
-#endif
-        }
-#if !(defined(IPDM_PROBE) && (IPDM_PROBE & 8))
-        if constexpr (st == 2) load_A(afr[1], p0 + 1, ch, cur_g.co_tile, 1);
-        if constexpr (st == 3) load_A(afr[0], p0, a_chunk, a_cot, 0);
-#endif
-        const bf16x8 bh = bs[pi][0], bm = bs[pi][1], bl = bs[pi][2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          f32x16 v = acc[pi][cp * 2 + c];
-          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][c][2], bh, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][c][0], bl, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][c][1], bm, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][c][1], bh, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][c][0], bm, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][c][0], bh, v, 0, 0, 0);
-          acc[pi][cp * 2 + c] = v;
-        }
-        if constexpr (st == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // the patch reads
-        if constexpr (st == 1) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // position p0+1's V reads
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x006, st < 2 ? 6 : 2, 0);
-          if constexpr (st == 0) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (st == 0) __syncthreads();               // everyone has read the raw stage
-      });
-      __builtin_amdgcn_s_waitcnt(0);                          // the DMA has landed
-      __syncthreads();
-    }
-    if (a.dbg) t2 = __builtin_amdgcn_s_memtime();
-
-    // ---- epilogue: four rounds (channel tile ct) through the exchange buffer ----
-    const int etile = tid & 31, ecg = tid >> 5;               // this thread: tile, channels 2*ecg, 2*ecg+1 of the 32
-    const int co0 = cur_g.co_tile * 128;
-    const int oy = cur_g.y0 + 2 * (etile / TX), ox = cur_g.x0 + 2 * (etile % TX);
-    const bool out_ok = oy < a.H && ox < a.W;
-    static_for<4>([&](auto rc) {
-      constexpr int ct = decltype(rc)::value;
-#pragma unroll
-      for (int pi = 0; pi < 2; ++pi)
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          const int col = (rr & 3) + 8 * (rr >> 2) + 4 * h;
-          ms[((p0 + pi) * 32 + col) * 32 + j] = acc[pi][ct][rr];
-        }
-      __syncthreads();
-      if (out_ok) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int cl = ecg * 2 + i;
-          const int co = co0 + ct * 32 + cl;
-          float m[16];
-#pragma unroll
-          for (int p = 0; p < 16; ++p) m[p] = ms[(p * 32 + cl) * 32 + etile];
-          float tt[2][4];
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            tt[0][qq] = m[0 * 4 + qq] + m[1 * 4 + qq] + m[2 * 4 + qq];
-            tt[1][qq] = m[1 * 4 + qq] - m[2 * 4 + qq] - m[3 * 4 + qq];
-          }
-          const float bias = a.bias ? a.bias[co] : 0.f;
-#pragma unroll
-          for (int ii = 0; ii < 2; ++ii) {
-            float y0v = tt[ii][0] + tt[ii][1] + tt[ii][2] + bias;
-            float y1v = tt[ii][1] - tt[ii][2] - tt[ii][3] + bias;
-            const size_t o = ((size_t)cur_g.b * a.Cout + co) * HW + (size_t)(oy + ii) * a.W + ox;
-            if (a.residual) {
-              const float2 rr2 = IPDM_NT_LOAD2(a.residual + o);
-              y0v += rr2.x;
-              y1v += rr2.y;
-            }
-            if (a.out) IPDM_NT_STORE2(a.out + o, y0v, y1v);
-            if (a.out_act) {
-              const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
-              const float e1 = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
-              IPDM_NT_STORE2(a.out_act + o, e0, e1);
-            }
-          }
-        }
-      }
-      __syncthreads();
-    });
-    if (!has_next) break;
-    zero_acc();
-    tile = next_tile;
-    cur_g = next_g;
-  }
-  if (a.dbg) {
-    __builtin_amdgcn_s_waitcnt(0);
-    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-    if (tid == 0) {
-      unsigned long long* d4 = a.dbg + (size_t)blockIdx.x * 4;
-      d4[0] = t0; d4[1] = t1; d4[2] = t2; d4[3] = t3;
-    }
-  }
-}
-
 bool x_small(const ConvArgs& a) { return a.W < 32 || a.dil > 1; }
 // undilated images of up to 16 x 16 pixels with enough (image, channel tile) pairs to fill the chip: the persistent
 // LDS-DMA kernel with an 8 x 8 tile block per image
@@ -1379,20 +1266,21 @@ bool x_poly(const ConvArgs& a) {
          !a.pool2 && !a.stats && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
 }
 
-int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
+template <bool HXV>
+static int conv_wino_bx3_launch_t(ConvArgs a, hipStream_t s) {
   if (x_poly(a)) {
     a.tiles_x = a.tiles_y = 1;
     a.co_tiles = a.Cout / X_CO;
     const int64_t nblk = (int64_t)a.B * a.co_tiles;
     static bool poly_attr = false;
     if (!poly_attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, true, false, false, false, true>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<HXV, 8, 8, true, true, false, false, false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
       poly_attr = true;
     }
     const int per_xcd = (int)((nblk + 7) / 8);
     const int S = per_xcd < cus_per_xcd() ? per_xcd : cus_per_xcd();
-    hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<8, 8, true, true, false, false, false, true>), dim3((unsigned)(8 * S)),
+    hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<HXV, 8, 8, true, true, false, false, false, true>), dim3((unsigned)(8 * S)),
                        dim3(512), X_LDS_BYTES, s, a, (int)nblk);
     return ipdm_launch_status();
   }
@@ -1416,58 +1304,21 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    const void* kernels[] = {reinterpret_cast<const void*>(conv_wino_bx3_kernel<false>),
-                             reinterpret_cast<const void*>(conv_wino_bx3_kernel<true>),
-                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, false>),
-                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, false>),
-                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, true>),
-                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, true>),
-                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, false, true>),
-                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, true, true>),
-                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, true, false, true>),
-                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<16, 4, false, true, true, true>)};
+    const void* kernels[] = {reinterpret_cast<const void*>(conv_wino_bx3_kernel<HXV, false>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_kernel<HXV, true>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<HXV, 16, 4, false, false>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<HXV, 8, 8, true, false>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<HXV, 16, 4, false, true>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<HXV, 8, 8, true, true>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<HXV, 16, 4, false, false, true>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<HXV, 16, 4, false, true, true>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<HXV, 16, 4, false, true, false, true>),
+                             reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<HXV, 16, 4, false, true, true, true>)};
     for (const void* k : kernels) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS_BYTES);
       if (e != hipSuccess) return (int)e;
     }
     attr_set = true;
-  }
-  // IPDM_WBX3_C128=1 selects the 128-channel x 32-tile form.  Off by default: it wins 3-15 % per layer in isolation
-  // (scripts/bench_conv.py) but loses 2.7 % on the whole iteration (26.07 vs 25.37 ms, same box, alternating runs) --
-  // its doubled fragment traffic costs more clock under the sustained power limit than the halved VALU work returns.
-  static int use_c128 = -1;
-  if (use_c128 < 0) {
-    const char* e = getenv("IPDM_WBX3_C128");
-    use_c128 = e ? atoi(e) : 0;
-  }
-  if (use_c128 && !a.pool2 && !a.stats && wino_persist() && a.Cout % 128 == 0 && a.Cin >= 2 * X_KC && (small_dma || !small)) {
-    // 128 channels x 32 tiles per workgroup: 16 x 2 tiles (4 x 32 pixels) on wide images, 8 x 4 (8 x 16) on small ones
-    static bool attr2 = false;
-    if (!attr2) {
-      const void* ks[] = {reinterpret_cast<const void*>(conv_wino_bx3_c128_kernel<16, 2, false>),
-                          reinterpret_cast<const void*>(conv_wino_bx3_c128_kernel<8, 4, true>)};
-      for (const void* k : ks) {
-        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Y_LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-      }
-      attr2 = true;
-    }
-    if (small_dma) {
-      a.tiles_x = (a.W + 15) / 16;
-      a.tiles_y = (a.H + 7) / 8;
-    } else {
-      a.tiles_x = (a.W + 31) / 32;
-      a.tiles_y = (a.H + 3) / 4;
-    }
-    const int64_t n2 = (int64_t)a.B * a.tiles_x * a.tiles_y * (a.Cout / 128);
-    if (n2 > 0x7fffffff) return IPDM_EUNSUPPORTED;
-    const int px = (int)((n2 + 7) / 8);
-    const int S2 = px < cus_per_xcd() ? px : cus_per_xcd();
-    if (small_dma)
-      hipLaunchKernelGGL((conv_wino_bx3_c128_kernel<8, 4, true>), dim3((unsigned)(8 * S2)), dim3(512), Y_LDS_BYTES, s, a, (int)n2);
-    else
-      hipLaunchKernelGGL((conv_wino_bx3_c128_kernel<16, 2, false>), dim3((unsigned)(8 * S2)), dim3(512), Y_LDS_BYTES, s, a, (int)n2);
-    return ipdm_launch_status();
   }
   const int per_xcd = (int)((nblk + 7) / 8);
   const int S = per_xcd < cus_per_xcd() ? per_xcd : cus_per_xcd();    // one 128+24 KiB workgroup per CU
@@ -1480,32 +1331,36 @@ int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
   if (a.stats && (small || !wino_persist() || a.Cin < 2 * X_KC)) return IPDM_EUNSUPPORTED;
   if (small_dma) {
     if (dma4)
-      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<8, 8, true, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<HXV, 8, 8, true, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
     else
-      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<8, 8, true, false>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<HXV, 8, 8, true, false>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
   } else if (small) {
-    hipLaunchKernelGGL(conv_wino_bx3_kernel<true>, dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv_wino_bx3_kernel<HXV, true>), dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
   } else if (wino_persist() && a.Cin >= 2 * X_KC) {
     if (a.stats) {
       if (!dma4) return IPDM_EUNSUPPORTED;
       if (a.pool2)
-        hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false, true, true, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+        hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<HXV, 16, 4, false, true, true, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
       else
-        hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false, true, false, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+        hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<HXV, 16, 4, false, true, false, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
       return ipdm_launch_status();
     }
     if (a.pool2 && dma4)
-      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false, true, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<HXV, 16, 4, false, true, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
     else if (a.pool2)
-      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false, false, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<HXV, 16, 4, false, false, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
     else if (dma4)
-      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<HXV, 16, 4, false, true>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
     else
-      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<16, 4, false, false>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+      hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<HXV, 16, 4, false, false>), dim3((unsigned)(8 * S)), dim3(512), X_LDS_BYTES, s, a, (int)nblk);
   } else {
-    hipLaunchKernelGGL(conv_wino_bx3_kernel<false>, dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv_wino_bx3_kernel<HXV, false>), dim3((unsigned)nblk), dim3(512), X_LDS_BYTES, s, a);
   }
   return ipdm_launch_status();
+}
+
+int conv_wino_bx3_launch(ConvArgs a, hipStream_t s) {
+  return a.hx ? conv_wino_bx3_launch_t<true>(a, s) : conv_wino_bx3_launch_t<false>(a, s);
 }
 
 // K parts that pay for a layer shape (a function of the SHAPE only, so that a sample's bits do not depend on its batch):
@@ -1523,7 +1378,8 @@ int wino_bx3_ksplit_for(int Cin, int Cout, int H, int W, int dilation) {
   return 2;
 }
 
-int conv_wino_bx3_launch_ksplit(ConvArgs a, int ksplit, float* work, hipStream_t s) {
+template <bool HXV>
+static int conv_wino_bx3_launch_ksplit_t(ConvArgs a, int ksplit, float* work, hipStream_t s) {
   if (ksplit != wino_bx3_ksplit_for(a.Cin, a.Cout, a.H, a.W, a.dil) || ksplit < 2 || !work) return IPDM_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a.x) & 15) != 0) return IPDM_EUNSUPPORTED;          // 16-byte LDS-DMA form only
   const float* bias = a.bias;
@@ -1539,18 +1395,22 @@ int conv_wino_bx3_launch_ksplit(ConvArgs a, int ksplit, float* work, hipStream_t
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<8, 8, true, true, false, false, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<HXV, 8, 8, true, true, false, false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
     attr_set = true;
   }
   const int per_xcd = (int)((nblk + 7) / 8);
   const int S = per_xcd < cus_per_xcd() ? per_xcd : cus_per_xcd();
-  hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<8, 8, true, true, false, false, true>), dim3((unsigned)(8 * S)), dim3(512),
+  hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<HXV, 8, 8, true, true, false, false, true>), dim3((unsigned)(8 * S)), dim3(512),
                      X_LDS_BYTES, s, a, (int)nblk);
   const int64_t plane = (int64_t)a.H * a.W, total = (int64_t)a.B * a.Cout * plane;
   hipLaunchKernelGGL(bx3_splitk_reduce_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, s, work, ksplit, bias, residual,
                      out, out_act, a.act_out, a.Cout, plane, total);
   return ipdm_launch_status();
+}
+
+int conv_wino_bx3_launch_ksplit(ConvArgs a, int ksplit, float* work, hipStream_t s) {
+  return a.hx ? conv_wino_bx3_launch_ksplit_t<true>(a, ksplit, work, s) : conv_wino_bx3_launch_ksplit_t<false>(a, ksplit, work, s);
 }
 
 int conv_wino_bx3_weights(const float* w, void* U, int Cout, int Cin, hipStream_t s) {
@@ -1561,9 +1421,29 @@ int conv_wino_bx3_weights(const float* w, void* U, int Cout, int Cin, hipStream_
   return ipdm_launch_status();
 }
 
+int conv_wino_hx2_weights(const float* w, void* U, int Cout, int Cin, hipStream_t s) {
+  const int n_cc = (Cin + 15) / 16, n_ct = (Cout + 31) / 32;
+  const int64_t total = (int64_t)16 * n_cc * n_ct * 512;
+  float* inv_scale = reinterpret_cast<float*>(static_cast<char*>(U) + total * 2 * 2);      // behind the two fp16 pieces
+  hipLaunchKernelGGL(wino_hx2_scale_kernel, dim3(n_ct * 32), dim3(256), 0, s, w, inv_scale, Cout, Cin, n_ct * 32);
+  hipLaunchKernelGGL(wino_hx2_weight_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, s, w, (unsigned short*)U, inv_scale,
+                     Cout, Cin, n_cc, n_ct);
+  return ipdm_launch_status();
+}
+
 }  // namespace ipdm_conv
 
 using namespace ipdm_conv;
+
+extern "C" int64_t ipdm_conv_wino_hx2_weight_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0) return -1;
+  return (int64_t)16 * ((Cin + 15) / 16) * ((Cout + 31) / 32) * 2048 + (int64_t)((Cout + 31) / 32) * 32 * 4;
+}
+
+extern "C" int ipdm_conv_wino_hx2_pack_weight(const float* w, void* U, int Cout, int Cin, void* stream) {
+  IPDM_REQUIRE(w && U && Cout > 0 && Cin > 0);
+  return conv_wino_hx2_weights(w, U, Cout, Cin, ipdm_stream(stream));
+}
 
 extern "C" int64_t ipdm_conv_wino_bx3_weight_bytes(int Cout, int Cin) {
   if (Cout <= 0 || Cin <= 0) return -1;
@@ -1584,7 +1464,7 @@ extern "C" int ipdm_conv2d_wino_bx3_supported(int Cin, int Cout, int H, int W, i
 
 static int wino_bx3_entry(const float* x, const void* U, const float* bias, const float* residual, float* out,
                           float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation, int pool2,
-                          float* stats, void* stream) {
+                          float* stats, void* stream, int hx = 0) {
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && dilation >= 1);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && U && (out || out_act) && x != out && x != out_act);
@@ -1594,6 +1474,7 @@ static int wino_bx3_entry(const float* x, const void* U, const float* bias, cons
   a.D = 1; a.kd = 1; a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
   a.pool2 = pool2 ? 1 : 0;
   a.stats = stats;
+  a.hx = hx;
   if (!wino_bx3_ok(a, 3)) return IPDM_EUNSUPPORTED;
   return conv_wino_bx3_launch(a, ipdm_stream(stream));
 }
@@ -1614,9 +1495,9 @@ extern "C" int ipdm_conv2d_wino_bx3_splitk(int Cin, int Cout, int H, int W, int 
   return wino_bx3_ksplit_for(Cin, Cout, H, W, dilation);
 }
 
-extern "C" int ipdm_conv2d_wino_bx3_splitk_f32(const float* x, const void* U, const float* bias, const float* residual,
-                                               float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H,
-                                               int W, int dilation, int ksplit, float* work, void* stream) {
+static int wino_bx3_splitk_entry(const float* x, const void* U, const float* bias, const float* residual, float* out,
+                                 float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation, int ksplit,
+                                 float* work, void* stream, int hx) {
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && dilation >= 1 && ksplit >= 2);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && U && work && (out || out_act) && x != out && x != out_act);
@@ -1624,8 +1505,29 @@ extern "C" int ipdm_conv2d_wino_bx3_splitk_f32(const float* x, const void* U, co
   a.x = x; a.wt = (const float*)U; a.bias = bias; a.coef = nullptr; a.residual = residual; a.out = out; a.out_act = out_act;
   a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = dilation; a.act = IPDM_ACT_NONE;
   a.D = 1; a.kd = 1; a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = nullptr;
+  a.hx = hx;
   if (!wino_bx3_ok(a, 3)) return IPDM_EUNSUPPORTED;
   return conv_wino_bx3_launch_ksplit(a, ksplit, work, ipdm_stream(stream));
+}
+
+extern "C" int ipdm_conv2d_wino_bx3_splitk_f32(const float* x, const void* U, const float* bias, const float* residual,
+                                               float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H,
+                                               int W, int dilation, int ksplit, float* work, void* stream) {
+  return wino_bx3_splitk_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, ksplit, work, stream, 0);
+}
+
+/* f16x2 forms of the three calls above: same arguments, U from ipdm_conv_wino_hx2_pack_weight (conv_kernel.h: two fp16
+ * pieces, three MFMAs per product; the shape rules -- _supported, _splitk, _stats_partials -- are shared) */
+extern "C" int ipdm_conv2d_wino_hx2_f32(const float* x, const void* U, const float* bias, const float* residual,
+                                        float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H, int W,
+                                        int dilation, int pool2, void* stream) {
+  return wino_bx3_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, pool2, nullptr, stream, 1);
+}
+
+extern "C" int ipdm_conv2d_wino_hx2_splitk_f32(const float* x, const void* U, const float* bias, const float* residual,
+                                               float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H,
+                                               int W, int dilation, int ksplit, float* work, void* stream) {
+  return wino_bx3_splitk_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, ksplit, work, stream, 1);
 }
 
 // partials per plane the statistics epilogue writes for this layer shape (0: that epilogue does not serve it)
@@ -1644,4 +1546,12 @@ extern "C" int ipdm_conv2d_wino_bx3_stats_f32(const float* x, const void* U, con
   IPDM_REQUIRE(stats != nullptr);
   if (ipdm_conv2d_wino_bx3_stats_partials(Cin, Cout, H, W, dilation, pool2) == 0) return IPDM_EUNSUPPORTED;
   return wino_bx3_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, pool2, stats, stream);
+}
+
+extern "C" int ipdm_conv2d_wino_hx2_stats_f32(const float* x, const void* U, const float* bias, const float* residual,
+                                              float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H,
+                                              int W, int dilation, int pool2, float* stats, void* stream) {
+  IPDM_REQUIRE(stats != nullptr);
+  if (ipdm_conv2d_wino_bx3_stats_partials(Cin, Cout, H, W, dilation, pool2) == 0) return IPDM_EUNSUPPORTED;
+  return wino_bx3_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, pool2, stats, stream, 1);
 }

@@ -78,7 +78,7 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
         return self._cached("wino_f32", ops.conv_wino_weight)
 
     def packed_wino_bx3(self):
-        return self._cached("wino_bx3", ops.conv_wino_bx3_weight)
+        return self._cached("wino_" + ops.CONV_IMPL, ops.conv_wino_split_weight)
 
     def packed(self):
         return self._cached("direct_" + ops.CONV_IMPL, ops.conv_weight)
@@ -98,7 +98,7 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
                 and ops.conv_wino_supported(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation)):
             return ops.conv2d_wino(x, self.packed_wino(), bias, residual, act_out=act_out, raw=raw,
                                    dilation=self.dilation)
-        if (USE_WINOGRAD and ops.CONV_IMPL == "bx3" and self.ndim == 2 and self.kernel_size == 3 and coef is None
+        if (USE_WINOGRAD and ops.split_impl() and self.ndim == 2 and self.kernel_size == 3 and coef is None
                 and act == ops.ACT_NONE and out is None and ops.wino_bx3_pays(self.in_planes, self.out_planes, x.shape[2],
                                                                               x.shape[3], self.dilation)):
             return ops.conv2d_wino_bx3(x, self.packed_wino_bx3(), bias, residual, act_out=act_out, raw=raw,
@@ -147,7 +147,7 @@ class ConvMeanPool(nn.Module):
         """3x3 ConvMeanPool (+ pooled-size residual, + activated copy) in ONE launch: the Winograd kernel's 2x2 output tile
         is the pooling window.  -> out or (out, out_act); None where the pooled epilogue is not built for this layer."""
         c = self.conv
-        if not (FUSE_POOL and USE_WINOGRAD and ops.CONV_IMPL == "bx3" and c.ndim == 2 and c.kernel_size == 3 and c.dilation == 1
+        if not (FUSE_POOL and USE_WINOGRAD and ops.split_impl() and c.ndim == 2 and c.kernel_size == 3 and c.dilation == 1
                 and inputs.shape[2] % 2 == 0 and inputs.shape[3] % 2 == 0
                 and ops.wino_bx3_pays(c.in_planes, c.out_planes, inputs.shape[2], inputs.shape[3], 1)):
             return None

@@ -687,13 +687,21 @@ def conv3x3_thin(x, weight, bias=None, coef=None):
     return out
 
 
-# ---- convolution on the bf16 matrix cores (exact three-way split) ---------------------------------------------
+# ---- fp32 convolution on the 16-bit matrix cores (exactly split operands) ---------------------------------------
 # Which kernel family the modules use (conv_weight()):
-#   "bx3" (default): fp32-faithful split-bf16 kernels (conv_bx3.hip) -- 2.67x the fp32 MFMA rate
+#   "hx2" (default): operands as two fp16 pieces, three fp16 MFMAs per product (csrc/conv_kernel.h) -- fp32-faithful
+#                    for |activation| < 16376, NaN (never a wrong finite value) beyond
+#   "bx3":           operands as three bf16 pieces, six bf16 MFMAs per product -- the whole fp32 exponent range
 #   "f32":           the fp32-MFMA direct kernel + fp32 Winograd (conv.hip / conv_wino.hip)
-CONV_IMPL = os.environ.get("IPDM_CONV_IMPL", "bx3")
-if CONV_IMPL not in ("bx3", "f32"):
-    raise ValueError(f"IPDM_CONV_IMPL={CONV_IMPL!r}: expected 'bx3' or 'f32'")
+CONV_IMPL = os.environ.get("IPDM_CONV_IMPL", "hx2")
+SPLIT_IMPLS = ("hx2", "bx3")
+if CONV_IMPL not in SPLIT_IMPLS + ("f32",):
+    raise ValueError(f"IPDM_CONV_IMPL={CONV_IMPL!r}: expected 'hx2', 'bx3' or 'f32'")
+
+
+def split_impl():
+    """True when the modules run the split-operand kernels (conv_bx3.hip / conv_wino_bx3.hip)"""
+    return CONV_IMPL in SPLIT_IMPLS
 
 
 class PackedWeightCache:
@@ -730,19 +738,26 @@ class PackedWeightMixin:
 
 def conv_weight(w):
     """pack a convolution weight for the selected kernel family; pass the result to conv2d / conv3d"""
-    return conv_bx3_weight(w) if CONV_IMPL == "bx3" else conv_pack_weight(w)
+    return conv_bx3_weight(w, fmt=CONV_IMPL) if split_impl() else conv_pack_weight(w)
 
 
 class PackedBx3:
-    """weights split into three bf16 pieces and laid out as MFMA A-fragments (ipdm_conv_bx3_pack_weight)"""
-    __slots__ = ("blob", "Cout", "Cin", "kk")
+    """weights split into 16-bit pieces and laid out as MFMA A-fragments: fmt "bx3" = three bf16 pieces
+    (ipdm_conv_bx3_pack_weight), "hx2" = two fp16 pieces + per-output-channel inverse scales (ipdm_conv_hx2_pack_weight)"""
+    __slots__ = ("blob", "Cout", "Cin", "kk", "fmt")
 
-    def __init__(self, blob, Cout, Cin, kk):
-        self.blob, self.Cout, self.Cin, self.kk = blob, Cout, Cin, kk
+    def __init__(self, blob, Cout, Cin, kk, fmt="bx3"):
+        self.blob, self.Cout, self.Cin, self.kk, self.fmt = blob, Cout, Cin, kk, fmt
 
 
-def conv_bx3_weight(w):
+def conv_hx2_weight(w):
+    return conv_bx3_weight(w, fmt="hx2")
+
+
+def conv_bx3_weight(w, fmt="bx3"):
     """[Cout, Cin, k, k] (k = 1 or 3) or [Cout, Cin, 3, 3, 3] / [Cout, Cin, 1, 1, 1] -> PackedBx3"""
+    if fmt not in SPLIT_IMPLS:
+        raise ValueError(f"conv_bx3_weight: fmt {fmt!r}")
     w = _gpu(w, torch.float32, "weight")
     Cout, Cin = w.shape[:2]
     kk = 1
@@ -754,10 +769,10 @@ def conv_bx3_weight(w):
         k = 27 if kk == 27 else 1
     else:
         k = {1: 1, 9: 3}[kk]
-    nbytes = _lib.lib.ipdm_conv_bx3_weight_bytes(Cout, Cin, k)
+    nbytes = getattr(_lib.lib, f"ipdm_conv_{fmt}_weight_bytes")(Cout, Cin, k)
     blob = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    call("ipdm_conv_bx3_pack_weight", _ptr(w), _ptr(blob), Cout, Cin, k, _stream())
-    return PackedBx3(blob, Cout, Cin, kk)
+    call(f"ipdm_conv_{fmt}_pack_weight", _ptr(w), _ptr(blob), Cout, Cin, k, _stream())
+    return PackedBx3(blob, Cout, Cin, kk, fmt)
 
 
 def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, out=None, act_out=ACT_NONE, raw=True):
@@ -789,29 +804,41 @@ def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=
     ksplit = _lib.lib.ipdm_conv_bx3_splitk(B, D, Cin, wq.Cout, H, W, k, dilation) if B else 1
     if ksplit > 1:        # too few tiles to fill the chip: deal the K loop to several workgroups per tile
         work = torch.empty((ksplit,) + shape, dtype=torch.float32, device=x.device)
-        call("ipdm_conv_bx3_splitk_f32", _ptr(x), _ptr(wq.blob), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
+        call(f"ipdm_conv_{wq.fmt}_splitk_f32", _ptr(x), _ptr(wq.blob), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
              _ptr(out_act), act_out, B, Cin, wq.Cout, D, H, W, k, dilation, int(vol), ksplit, _ptr(work), _stream())
     elif vol:
-        call("ipdm_conv3d_bx3_f32", _ptr(x), _ptr(wq.blob), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
+        call(f"ipdm_conv3d_{wq.fmt}_f32", _ptr(x), _ptr(wq.blob), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
              _ptr(out_act), act_out, B, Cin, wq.Cout, D, H, W, k, dilation, _stream())
     else:
-        call("ipdm_conv2d_bx3_f32", _ptr(x), _ptr(wq.blob), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
+        call(f"ipdm_conv2d_{wq.fmt}_f32", _ptr(x), _ptr(wq.blob), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
              _ptr(out_act), act_out, B, Cin, wq.Cout, H, W, k, dilation, _stream())
     if CONV_TRACE is not None:
         e1.record()
-        CONV_TRACE.append(dict(B=B * D, Cin=Cin, Cout=wq.Cout, H=H, W=W, k=k, dil=dilation, bx3=True, res=residual is not None,
+        CONV_TRACE.append(dict(B=B * D, Cin=Cin, Cout=wq.Cout, H=H, W=W, k=k, dil=dilation, bx3=True, fmt=wq.fmt, res=residual is not None,
                                n_out=int(raw) + int(want_act),
                                taps3d=wq.kk if vol else None, e0=e0, e1=e1))
     return (out, out_act) if want_act else out
 
 
-def conv_wino_bx3_weight(w):
-    """[Cout, Cin, 3, 3] -> Winograd-domain weights, split into bf16 pieces in MFMA fragment order (PackedBx3, kk=16)"""
+def conv_wino_bx3_weight(w, fmt="bx3"):
+    """[Cout, Cin, 3, 3] -> Winograd-domain weights, split into 16-bit pieces in MFMA fragment order (PackedBx3, kk=16)"""
+    if fmt not in SPLIT_IMPLS:
+        raise ValueError(f"conv_wino_bx3_weight: fmt {fmt!r}")
     w = _gpu(w, torch.float32, "weight")
     Cout, Cin = w.shape[:2]
-    blob = torch.empty(_lib.lib.ipdm_conv_wino_bx3_weight_bytes(Cout, Cin), dtype=torch.uint8, device=w.device)
-    call("ipdm_conv_wino_bx3_pack_weight", _ptr(w), _ptr(blob), Cout, Cin, _stream())
-    return PackedBx3(blob, Cout, Cin, 16)
+    nbytes = getattr(_lib.lib, f"ipdm_conv_wino_{fmt}_weight_bytes")(Cout, Cin)
+    blob = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    call(f"ipdm_conv_wino_{fmt}_pack_weight", _ptr(w), _ptr(blob), Cout, Cin, _stream())
+    return PackedBx3(blob, Cout, Cin, 16, fmt)
+
+
+def conv_wino_hx2_weight(w):
+    return conv_wino_bx3_weight(w, fmt="hx2")
+
+
+def conv_wino_split_weight(w):
+    """Winograd-domain weights for the selected split family (CONV_IMPL = "hx2" / "bx3")"""
+    return conv_wino_bx3_weight(w, fmt=CONV_IMPL if split_impl() else "bx3")
 
 
 def conv_wino_bx3_supported(Cin, Cout, H, W, dilation=1):
@@ -844,13 +871,13 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
         for b0 in range(0, B, nb):
             b1 = min(B, b0 + nb)
             work = torch.empty((ksplit, b1 - b0, Cout, H, W), dtype=torch.float32, device=x.device)
-            call("ipdm_conv2d_wino_bx3_splitk_f32", _ptr(x[b0:b1]), _ptr(U.blob), _ptr(bias),
+            call(f"ipdm_conv2d_wino_{U.fmt}_splitk_f32", _ptr(x[b0:b1]), _ptr(U.blob), _ptr(bias),
                  _ptr(None if residual is None else residual[b0:b1]), _ptr(None if out is None else out[b0:b1]),
                  _ptr(None if out_act is None else out_act[b0:b1]), act_out, b1 - b0, Cin, Cout, H, W, dilation, ksplit,
                  _ptr(work), _stream())
         if CONV_TRACE is not None:
             e1.record()
-            CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, res=residual is not None,
+            CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, fmt=U.fmt, res=residual is not None,
                                    n_out=int(raw) + int(want_act), pool2=False, ksplit=ksplit, e0=e0, e1=e1))
         return (out, out_act) if want_act else out
     part = None
@@ -866,16 +893,16 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
                 int(bool(pool2)))
         if part is not None:
             try:
-                call("ipdm_conv2d_wino_bx3_stats_f32", *args, _ptr(part[b0:b1]), _stream())
+                call(f"ipdm_conv2d_wino_{U.fmt}_stats_f32", *args, _ptr(part[b0:b1]), _stream())
                 continue
             except _lib.IpdmUnsupported:         # e.g. IPDM_WBX3_DMA4=0: no statistics epilogue on that kernel form
                 part = None
-        call("ipdm_conv2d_wino_bx3_f32", *args, _stream())
+        call(f"ipdm_conv2d_wino_{U.fmt}_f32", *args, _stream())
     if part is not None:
         out._ipdm_partials = part
     if CONV_TRACE is not None:
         e1.record()
-        CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, res=residual is not None,
+        CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, fmt=U.fmt, res=residual is not None,
                                n_out=int(raw) + int(want_act), pool2=bool(pool2), e0=e0, e1=e1))
     return (out, out_act) if want_act else out
 

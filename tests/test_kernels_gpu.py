@@ -585,7 +585,8 @@ def test_msf_block_3d_unequal_volumes(ops):
 @pytest.mark.parametrize("B,Cin,Cout,H,W,pool,res", [(2, 128, 128, 64, 64, False, True), (3, 32, 64, 40, 36, False, False),
                                                      (2, 64, 128, 64, 32, True, True), (1, 32, 64, 34, 44, True, False),
                                                      (2, 32, 64, 32, 32, False, True)])
-def test_wino_bx3_statistics_epilogue(ops, B, Cin, Cout, H, W, pool, res):
+@pytest.mark.parametrize("fmt", ["bx3", "hx2"])
+def test_wino_bx3_statistics_epilogue(ops, B, Cin, Cout, H, W, pool, res, fmt):
     """the Winograd kernel's statistics epilogue: the InstanceNorm++ coefficients from its partials equal those from a pass
     over the stored tensor (ragged tile blocks, pooled epilogue, residual); the result itself is bit-identical with and
     without the epilogue"""
@@ -596,7 +597,7 @@ def test_wino_bx3_statistics_epilogue(ops, B, Cin, Cout, H, W, pool, res):
     b = torch.randn(Cout, generator=gen).cuda()
     oh, ow = (H // 2, W // 2) if pool else (H, W)
     r = (torch.randn(B, Cout, oh, ow, generator=gen) * 3 + 5).cuda() if res else None      # a mean far from zero
-    U = ops.conv_wino_bx3_weight(w)
+    U = ops.conv_wino_bx3_weight(w, fmt=fmt)
     P = int(_lib.lib.ipdm_conv2d_wino_bx3_stats_partials(Cin, Cout, H, W, 1, int(pool)))
     assert P == 2 * ((W + 31) // 32) * ((H + 7) // 8)
     y0 = ops.conv2d_wino_bx3(x, U, b, r, pool2=pool)
@@ -618,7 +619,8 @@ def test_wino_bx3_statistics_epilogue(ops, B, Cin, Cout, H, W, pool, res):
 @pytest.mark.parametrize("B,Cin,Cout,H,W,res,act", [(3, 256, 256, 16, 16, True, True), (1, 64, 64, 16, 16, False, False),
                                                      (2, 512, 256, 16, 16, True, False), (2, 128, 128, 8, 16, False, True),
                                                      (5, 256, 128, 16, 12, True, True)])
-def test_wino_bx3_split_k(ops, B, Cin, Cout, H, W, res, act):
+@pytest.mark.parametrize("fmt", ["bx3", "hx2"])
+def test_wino_bx3_split_k(ops, B, Cin, Cout, H, W, res, act, fmt):
     """16-pixel layers with fewer than 512 output channels run as two K halves of the persistent Winograd kernel plus the
     fixed-order reduction: against a float64 convolution, and bit-identical whatever the batch around a sample"""
     gen = torch.Generator().manual_seed(43)
@@ -627,7 +629,7 @@ def test_wino_bx3_split_k(ops, B, Cin, Cout, H, W, res, act):
     b = torch.randn(Cout, generator=gen)
     r = torch.randn(B, Cout, H, W, generator=gen) if res else None
     assert ops.wino_bx3_splitk(Cin, Cout, H, W) == 2 and ops.wino_bx3_pays(Cin, Cout, H, W)
-    U = ops.conv_wino_bx3_weight(w.cuda())
+    U = ops.conv_wino_bx3_weight(w.cuda(), fmt=fmt)
     want = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     if res:
         want = want + r.double()
@@ -643,7 +645,8 @@ def test_wino_bx3_split_k(ops, B, Cin, Cout, H, W, res, act):
 
 @pytest.mark.parametrize("B,Cin,Cout,dil,res", [(3, 64, 64, 2, True), (2, 256, 512, 2, False), (1, 32, 128, 4, True),
                                                  (5, 128, 64, 4, False)])
-def test_wino_bx3_dilated_16px_polyphase(ops, B, Cin, Cout, dil, res):
+@pytest.mark.parametrize("fmt", ["bx3", "hx2"])
+def test_wino_bx3_dilated_16px_polyphase(ops, B, Cin, Cout, dil, res, fmt):
     """dilated 16 x 16 layers: the persistent kernel on the polyphase tile space (whole padded image in LDS) against a float64
     convolution, and independent of the batch around a sample"""
     gen = torch.Generator().manual_seed(47)
@@ -651,7 +654,7 @@ def test_wino_bx3_dilated_16px_polyphase(ops, B, Cin, Cout, dil, res):
     w = torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.05
     b = torch.randn(Cout, generator=gen)
     r = torch.randn(B, Cout, 16, 16, generator=gen) if res else None
-    U = ops.conv_wino_bx3_weight(w.cuda())
+    U = ops.conv_wino_bx3_weight(w.cuda(), fmt=fmt)
     want = F.conv2d(x.double(), w.double(), b.double(), padding=dil, dilation=dil)
     if res:
         want = want + r.double()
@@ -671,7 +674,8 @@ def test_wino_bx3_split_k_rule_is_shape_only(ops):
     assert ops.wino_bx3_splitk(256, 256, 16, 16) == 2
 
 
-def test_wino_bx3_statistics_epilogue_large_mean(ops):
+@pytest.mark.parametrize("fmt", ["bx3", "hx2"])
+def test_wino_bx3_statistics_epilogue_large_mean(ops, fmt):
     """planes with |mean| >> spread (1000 +- 1): the epilogue's one-pass sums are taken about a shift from the data, so the
     variance keeps the precision the two-pass kernel has"""
     gen = torch.Generator().manual_seed(42)
@@ -679,7 +683,7 @@ def test_wino_bx3_statistics_epilogue_large_mean(ops):
     x = torch.randn(B, Cin, H, W, generator=gen).cuda()
     w = (torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.05).cuda()
     r = (torch.randn(B, Cout, H, W, generator=gen) + 1000.0).cuda()
-    U = ops.conv_wino_bx3_weight(w)
+    U = ops.conv_wino_bx3_weight(w, fmt=fmt)
     y = ops.conv2d_wino_bx3(x, U, None, r, want_stats=True)
     assert hasattr(y, "_ipdm_partials")
     ones = torch.ones(Cout).cuda()
@@ -692,14 +696,15 @@ def test_wino_bx3_statistics_epilogue_large_mean(ops):
     assert (c_full[..., 1].double() / rstd - 1).abs().max() < 2e-4
 
 
-def test_wino_bx3_statistics_epilogue_unsupported(ops):
+@pytest.mark.parametrize("fmt", ["bx3", "hx2"])
+def test_wino_bx3_statistics_epilogue_unsupported(ops, fmt):
     from inverseproblemwithdiffusionmodel_amd import _lib
     lib = _lib.lib
     assert lib.ipdm_conv2d_wino_bx3_stats_partials(256, 256, 16, 16, 1, 0) == 0        # small-image kernels
     assert lib.ipdm_conv2d_wino_bx3_stats_partials(256, 256, 32, 32, 2, 0) == 0        # dilated
     assert lib.ipdm_conv2d_wino_bx3_stats_partials(16, 64, 64, 64, 1, 0) == 0          # one chunk: not the persistent kernel
     x = torch.randn(1, 256, 16, 16).cuda()
-    U = ops.conv_wino_bx3_weight(torch.randn(512, 256, 3, 3).cuda())
+    U = ops.conv_wino_bx3_weight(torch.randn(512, 256, 3, 3).cuda(), fmt=fmt)
     y = ops.conv2d_wino_bx3(x, U, want_stats=True)                                     # silently without partials
     assert not hasattr(y, "_ipdm_partials")
 
@@ -856,7 +861,8 @@ def test_conv2d_winograd(ops, B, Cin, Cout, H, W, res, dil):
     (2, 48, 64, 16, 16, 3, 4, False, "none", False),         # PW = 16 tiles with dilation 4
     (2, 20, 33, 9, 16, 1, 1, True, "elu", True),             # 1x1, ragged channels, fused norm + activation
 ])
-def test_conv_bx3(ops, B, Cin, Cout, H, W, k, dil, norm, actname, res):
+@pytest.mark.parametrize("fmt", ["bx3", "hx2"])
+def test_conv_bx3(ops, B, Cin, Cout, H, W, k, dil, norm, actname, res, fmt):
     gen = torch.Generator().manual_seed(13)
     x = torch.randn(B, Cin, H, W, generator=gen)
     w = torch.randn(Cout, Cin, k, k, generator=gen) / (Cin * k * k) ** 0.5
@@ -871,7 +877,7 @@ def test_conv_bx3(ops, B, Cin, Cout, H, W, k, dil, norm, actname, res):
         want = want + resid.double()
     xd = x.cuda()
     coef = ops.instnorm_plus_coef(xd, p["alpha"].cuda(), p["gamma"].cuda(), p["beta"].cuda()) if norm else None
-    wq = ops.conv_bx3_weight(w.cuda())
+    wq = ops.conv_bx3_weight(w.cuda(), fmt=fmt)
     got = ops.conv_bx3(xd, wq, bias.cuda(), coef, ops.ACT_CODES[actname], None if resid is None else resid.cuda(), dil)
     err = (got.cpu().double() - want).abs().max()
     # six-term split: the dropped products are < 2^-26 of |w x|, i.e. below the rounding of the fp32 accumulation
@@ -905,12 +911,42 @@ def test_conv_bx3_exactness_and_layout(ops):
     assert torch.equal(got2[0, :, 0, 0], vals * 0.5)
 
 
-def test_conv_bx3_activated_second_output(ops):
+def test_conv_hx2_exactness_and_layout(ops):
+    """the f16x2 twin of the test above: values with 22 significant bits inside fp16's exponent window are carried EXACTLY by
+    the two fp16 pieces (11 + 11 bits), so a channel permutation comes back bit-exact; weights with full fp32 significands
+    against power-of-two inputs lose at most the third piece (2^-24 relative: one fp32 rounding)"""
+    Cin = Cout = 64
+    gen = torch.Generator().manual_seed(16)
+    x = torch.randint(-2 ** 21, 2 ** 21, (2, Cin, 8, 32), generator=gen).float() * 2.0 ** -12
+    x[0, 0, 0, :4] = torch.tensor([1.0 + 2.0 ** -21, -(2.0 - 2.0 ** -20), 511.999755859375, -0.000244140625])
+    w = torch.zeros(Cout, Cin, 3, 3)
+    for c in range(Cout):
+        w[c, (c * 7 + 3) % Cin, 1, 1] = 1.0
+    got = ops.conv_bx3(x.cuda(), ops.conv_hx2_weight(w.cuda())).cpu()
+    assert torch.equal(got, x[:, [(c * 7 + 3) % Cin for c in range(Cout)]])
+    U = ops.conv_wino_hx2_weight(w.cuda())               # the Winograd form of the same permutation: exact transforms too
+    assert torch.equal(ops.conv2d_wino_bx3(x.cuda(), U).cpu(), got)
+    w2 = torch.zeros(32, 16, 1, 1)
+    vals = torch.randn(32, generator=gen)
+    w2[torch.arange(32), torch.arange(32) % 16, 0, 0] = vals
+    x2 = torch.full((1, 16, 4, 32), 0.5)
+    got2 = ops.conv_bx3(x2.cuda(), ops.conv_hx2_weight(w2.cuda())).cpu()
+    assert (got2[0, :, 0, 0] - vals * 0.5).abs().max() <= 2.0 ** -24 * (vals * 0.5).abs().max()
+    # the range contract: an activation beyond fp16's range gives a non-finite result, never a wrong finite one
+    x3 = x.clone()
+    x3[1, 5, 2, 3] = 1.0e5
+    got3 = ops.conv_bx3(x3.cuda(), ops.conv_hx2_weight(w.cuda())).cpu()
+    assert not torch.isfinite(got3[1, [c for c in range(Cout) if (c * 7 + 3) % Cin == 5][0], 2, 3])
+    assert torch.isfinite(got3[0]).all()
+
+
+@pytest.mark.parametrize("fmt", ["bx3", "hx2"])
+def test_conv_bx3_activated_second_output(ops, fmt):
     gen = torch.Generator().manual_seed(14)
     x = torch.randn(2, 64, 16, 32, generator=gen)
     w = torch.randn(64, 64, 3, 3, generator=gen) / 24
     resid = torch.randn(2, 64, 16, 32, generator=gen)
-    wq = ops.conv_bx3_weight(w.cuda())
+    wq = ops.conv_bx3_weight(w.cuda(), fmt=fmt)
     want = F.conv2d(x.double(), w.double(), padding=1) + resid.double()
     raw, act = ops.conv_bx3(x.cuda(), wq, residual=resid.cuda(), act_out=ops.ACT_ELU)
     assert (raw.cpu().double() - want).abs().max() < 4e-6
@@ -921,14 +957,15 @@ def test_conv_bx3_activated_second_output(ops):
 
 @pytest.mark.parametrize("dil,Cin,Cout,D,Hh,Ww", [(1, 8, 16, 8, 8, 24), (2, 16, 32, 8, 8, 12), (4, 32, 32, 8, 8, 24),
                                                   (1, 1, 8, 5, 6, 7), (2, 8, 1, 4, 8, 24), (1, 128, 128, 8, 8, 24)])
-def test_conv_bx3_3d(ops, dil, Cin, Cout, D, Hh, Ww):
+@pytest.mark.parametrize("fmt", ["bx3", "hx2"])
+def test_conv_bx3_3d(ops, dil, Cin, Cout, D, Hh, Ww, fmt):
     gen = torch.Generator().manual_seed(20)
     x = torch.randn(3, Cin, D, Hh, Ww, generator=gen)
     w = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (Cin * 27) ** 0.5
     b = torch.randn(Cout, generator=gen)
     r = torch.randn(3, Cout, D, Hh, Ww, generator=gen)
     want = F.conv3d(x.double(), w.double(), b.double(), padding=dil, dilation=dil) + r.double()
-    got = ops.conv3d(x.cuda(), ops.conv_bx3_weight(w.cuda()), b.cuda(), residual=r.cuda(), dilation=dil)
+    got = ops.conv3d(x.cuda(), ops.conv_bx3_weight(w.cuda(), fmt=fmt), b.cuda(), residual=r.cuda(), dilation=dil)
     assert (got.cpu().double() - want).abs().max() < 4e-6 * max(1.0, float(want.abs().max()))
 
 
@@ -939,7 +976,8 @@ def test_conv_bx3_3d(ops, dil, Cin, Cout, D, Hh, Ww):
     (3, 64, 64, 16, 16, True, 1), (2, 64, 128, 16, 16, True, 2), (2, 128, 64, 16, 16, False, 4),      # small / dilated
     (1, 16, 64, 24, 16, False, 2), (1, 16, 64, 32, 32, True, 2),
     (40, 32, 256, 16, 16, True, 1), (80, 32, 128, 12, 16, False, 1)])        # 16-pixel images, persistent DMA path
-def test_conv2d_winograd_bx3(ops, B, Cin, Cout, H, W, res, dil):
+@pytest.mark.parametrize("fmt", ["bx3", "hx2"])
+def test_conv2d_winograd_bx3(ops, B, Cin, Cout, H, W, res, dil, fmt):
     """split-bf16 F(2x2,3x3) path (LDS-DMA raw stage on wide images, register path on small / dilated ones) vs a
     float64 direct convolution"""
     assert ops.conv_wino_bx3_supported(Cin, Cout, H, W, dil)
@@ -952,7 +990,7 @@ def test_conv2d_winograd_bx3(ops, B, Cin, Cout, H, W, res, dil):
     want = F.conv2d(x.double(), w.double(), bias.double(), padding=dil, dilation=dil)
     if res:
         want = want + resid.double()
-    U = ops.conv_wino_bx3_weight(w.cuda())
+    U = ops.conv_wino_bx3_weight(w.cuda(), fmt=fmt)
     raw, act = ops.conv2d_wino_bx3(x.cuda(), U, bias.cuda(), None if resid is None else resid.cuda(), act_out=ops.ACT_ELU,
                                    dilation=dil)
     scale = max(1.0, float(want.abs().max()))
@@ -1007,7 +1045,8 @@ def test_device_metrics_match_host_definitions(ops):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(3, 128, 256, 64, 64), (2, 32, 64, 32, 96), (2, 64, 128, 40, 36)])
-def test_conv_wino_bx3_pooled_epilogue(ops, B, Cin, Cout, H, W):
+@pytest.mark.parametrize("fmt", ["bx3", "hx2"])
+def test_conv_wino_bx3_pooled_epilogue(ops, B, Cin, Cout, H, W, fmt):
     """ConvMeanPool in one launch (the Winograd output tile is the 2x2 pooling window): conv + bias -> 2x2 mean -> + pooled
     residual -> (ELU copy), against float64 torch, same 4e-6 bound as the unpooled kernel"""
     gen = torch.Generator().manual_seed(41)
@@ -1016,7 +1055,7 @@ def test_conv_wino_bx3_pooled_epilogue(ops, B, Cin, Cout, H, W):
     b = torch.randn(Cout, generator=gen)
     r = torch.randn(B, Cout, H // 2, W // 2, generator=gen)
     want = torch.nn.functional.avg_pool2d(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1), 2) + r.double()
-    U = ops.conv_wino_bx3_weight(w.cuda())
+    U = ops.conv_wino_bx3_weight(w.cuda(), fmt=fmt)
     out, out_act = ops.conv2d_wino_bx3(x.cuda(), U, b.cuda(), r.cuda(), act_out=ops.ACT_ELU, pool2=True)
     assert out.shape == (B, Cout, H // 2, W // 2)
     scale = float(want.abs().max())

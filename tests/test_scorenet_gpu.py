@@ -502,13 +502,15 @@ def test_full_size_trajectory_bf16x3_vs_fp32_mfma():
         finally:
             ops.CONV_IMPL = old
 
-    a, b = run("bx3"), run("f32")
-    assert np.isfinite(a).all() and a.shape == (2, 1, 128, 128)
-    for i in range(2):
-        ma, mb = np.abs(a[i]), np.abs(b[i])
-        assert metrics.nrmse(ma, mb) < 1e-5
-        assert abs(metrics.ssim(ma[0], mb[0]) - 1.0) < 1e-5
-    assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max()
+    b = run("f32")
+    for impl in ("hx2", "bx3"):                          # two fp16 pieces / three bf16 pieces vs the exact-fp32 MFMA kernels
+        a = run(impl)
+        assert np.isfinite(a).all() and a.shape == (2, 1, 128, 128)
+        for i in range(2):
+            ma, mb = np.abs(a[i]), np.abs(b[i])
+            assert metrics.nrmse(ma, mb) < 1e-5, impl
+            assert abs(metrics.ssim(ma[0], mb[0]) - 1.0) < 1e-5, impl
+        assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max(), impl
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
