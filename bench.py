@@ -161,6 +161,49 @@ def cpu_baseline(prob, steps_b1, steps_b8, mnist):
                 **out)
 
 
+def upfirdn2d_hbm(dev):
+    """north_star asks for upfirdn2d's HBM GB/s in the report: the largest call of an NCSN++ celebahq_256 forward at B = 8
+    (FIR down-sampling of (8,128,256,256): 268.4 MB read + 67.1 MB written = 335.5 MB algorithmic, and its up-sampling twin
+    (8,128,128,128) -> 256^2: 67.1 MB read + 268.4 MB written), 20 calls per hipGraph replay, HIP events on the launch
+    stream; `traffic_ratio` is the PMC measurement of profiles/r02_upfirdn2d_pmc.csv (FETCH x2 + WRITE over algorithmic)."""
+    from inverseproblemwithdiffusionmodel_amd.models import up_or_down_sampling as uds
+    res = {"peak": 8000.0, "unit": "GB/s", "traffic_ratio": 1.02, "traffic_source": "profiles/r02_upfirdn2d_pmc.csv"}
+
+    def timed(fn, iters=20):
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        best = 1e9
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / iters * 1e-3)
+        return best
+    try:
+        x = torch.randn(8, 128, 256, 256, device=dev)
+        t = timed(lambda: uds.downsample_2d(x, (1, 3, 3, 1), factor=2))
+        nb = 4 * x.numel() * 1.25
+        res["down2_8x128x256x256"] = {"algorithmic_MB": nb / 1e6, "us": t * 1e6, "achieved": nb / t / 1e9, "frac": nb / t / 1e9 / 8000.0}
+        x2 = torch.randn(8, 128, 128, 128, device=dev)
+        t2 = timed(lambda: uds.upsample_2d(x2, (1, 3, 3, 1), factor=2))
+        nb2 = 4 * x2.numel() * 5
+        res["up2_8x128x128x128"] = {"algorithmic_MB": nb2 / 1e6, "us": t2 * 1e6, "achieved": nb2 / t2 / 1e9, "frac": nb2 / t2 / 1e9 / 8000.0}
+        res["achieved"], res["frac"] = res["down2_8x128x256x256"]["achieved"], res["down2_8x128x256x256"]["frac"]
+        del x, x2
+        torch.cuda.empty_cache()
+    except Exception as e:                                    # never lose the headline line to the extra measurement
+        res["error"] = repr(e)[:300]
+    return res
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -236,7 +279,10 @@ def main():
         "metric": "ALD reconstructions/sec (128x128 complex, R=40, 4-coil)",
         "value": value, "unit": "reconstructions/s", "n_gpus": world, "steps": steps, "warmup": warm,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if ops.CONV_IMPL == "f32" else "f32 (convolutions: exact bf16x3 split on the bf16 MFMA, fp32 accumulate)",
+        "dtype": {"f32": "f32",
+                  "bx3": "f32 (convolutions: exact bf16x3 split on the bf16 MFMA, fp32 accumulate)",
+                  "hx2": "f32 (convolutions: operands as two fp16 pieces = 22 significand bits + 2 signs, three fp16 MFMAs per "
+                         "product, fp32 accumulate; error vs float64 <= the exact-fp32 MFMA kernel's, DESIGN.md 4.1e)"}[ops.CONV_IMPL],
         "data": "synthetic",
         "config": {
             "workload": "ACDC-style 128x128 complex SENSE R=40 4-coil ALD reconstruction, NCSNv2Deepest ngf=128 "
@@ -272,16 +318,26 @@ def main():
         conv_ms = float(np.median([sum(r["ms"] for r in rep) for rep in reps]))
         log(f"conv census: {len(reps[0])} launches, {conv_ms:.2f} ms, {flops / 1e12:.3f} TFLOP per step")
         achieved = flops / (conv_ms * 1e-3) / 1e12
-        traffic = None
+        # HBM traffic per conv launch comes from PMC counters, which only rocprofv3 can collect (scripts/profile_pmc.sh:
+        # separate FETCH_SIZE / WRITE_SIZE passes over THIS command); the number is therefore a recorded measurement and is
+        # stamped with the kernel family and source revision it was taken on -- it is dropped when the family differs
+        traffic, traffic_source = None, None
         pmc = os.path.join(REPO, "profiles", "conv_hbm_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                rec = json.load(f)
+            if rec.get("conv_impl", "bx3") == ops.CONV_IMPL:
+                traffic = rec.get("hbm_bytes_per_launch")
+                traffic_source = {k: rec.get(k) for k in ("conv_impl", "measured_at_commit", "measured_on", "launches_profiled")}
+                traffic_source["file"] = "profiles/conv_hbm_traffic.json"
         n_bx3 = sum(1 for r in reps[0] if r.get("bx3"))
-        # bf16 MFMA FLOPs actually executed: six per fp32 multiply-add, 2.25x fewer on the Winograd launches
+        mfma_per_product = 3.0 if ops.CONV_IMPL == "hx2" else 6.0
+        # 16-bit MFMA FLOPs actually executed: three (fp16 pair) or six (bf16 triple) per fp32 multiply-add, 2.25x fewer on
+        # the Winograd launches
         flops_bx3 = sum(r["flops"] / (2.25 if r.get("wino") else 1.0) for r in reps[0] if r.get("bx3"))
         common = {
-            "traffic": traffic, "algorithmic_bytes_per_launch": bytes_alg, "launches_per_step": len(reps[0]),
+            "traffic": traffic, "traffic_source": traffic_source,
+            "algorithmic_bytes_per_launch": bytes_alg, "launches_per_step": len(reps[0]),
             "avg_launch_ms": conv_ms / len(reps[0]), "algorithmic_flops_per_step": flops, "conv_ms_per_step": conv_ms,
             "conv_share_of_step": conv_ms / ms_per_step,
         }
@@ -292,18 +348,23 @@ def main():
             # 2.25x fewer on the Winograd launches) over the dense bf16 peak.  Winograd's saving is NOT counted as
             # utilisation; the algorithmic view (direct-convolution FLOPs over the fp32-equivalent roof
             # 2500 / 6) is carried beside it.
-            executed_tflops = 6.0 * flops_bx3 / (conv_ms * 1e-3) / 1e12
+            executed_tflops = mfma_per_product * flops_bx3 / (conv_ms * 1e-3) / 1e12
             out["roofline"] = dict({
                 "bound": "mfma", "achieved": executed_tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": executed_tflops / PEAK_BF16_MFMA_TFLOPS,
                 "kernel": "conv_wino_bx3_wide_kernel (Winograd F(2x2,3x3)) + conv_bx3_kernel<...> (direct): fp32 convolution as "
-                          "6 x v_mfma_f32_32x32x16_bf16 on exact bf16x3 operand splits, fp32 accumulate",
-                "achieved_note": "executed bf16 MFMA FLOPs (6 per fp32 multiply-add of the split, Winograd launches at 16/36 of "
-                                 "the direct multiply-adds) / measured conv time, against the dense bf16 MFMA peak",
-                "algorithmic": {"achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS / 6.0,
-                                "frac": achieved / (PEAK_BF16_MFMA_TFLOPS / 6.0), "unit": "TFLOP/s",
+                          + ("3 x v_mfma_f32_32x32x16_f16 on two-piece fp16 operand splits" if ops.CONV_IMPL == "hx2" else
+                             "6 x v_mfma_f32_32x32x16_bf16 on exact bf16x3 operand splits") + ", fp32 accumulate",
+                "mfma_per_fp32_product": mfma_per_product,
+                "achieved_note": "executed 16-bit MFMA FLOPs (mfma_per_fp32_product per fp32 multiply-add of the split, Winograd "
+                                 "launches at 16/36 of the direct multiply-adds) / measured conv time, against the dense "
+                                 "bf16 / fp16 MFMA peak (same rate)",
+                "algorithmic": {"achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS / mfma_per_product,
+                                "frac": achieved / (PEAK_BF16_MFMA_TFLOPS / mfma_per_product), "unit": "TFLOP/s",
+                                "frac_of_round2_roof": achieved / (PEAK_BF16_MFMA_TFLOPS / 6.0),
                                 "note": "direct-convolution fp32 FLOPs (2*MACs, SURVEY.md 8d: 209.59 GFLOP per image) / measured "
-                                        "conv time over the fp32-equivalent roof = bf16 peak / 6 MFMAs per product"},
+                                        "conv time over the fp32-equivalent roof = 16-bit MFMA peak / MFMAs per product; "
+                                        "frac_of_round2_roof prices the same rate against round 2's roof (peak / 6)"},
                 "bx3_launches": n_bx3, "winograd_launches": n_wino,
                 "fp32_mfma_peak_tflops": PEAK_FP32_MFMA_TFLOPS,
             }, **common)
@@ -317,28 +378,37 @@ def main():
                 "winograd_launches": n_wino, "executed_mfma_tflops": executed / (conv_ms * 1e-3) / 1e12,
                 "executed_mfma_frac": executed / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             }, **common)
-        if world == 1 and not args.full and not args.no_alt and ops.CONV_IMPL == "bx3":
-            # the same iteration through the exact-fp32-MFMA kernel family (conv_mfma_kernel + fp32 Winograd),
-            # reported beside the headline so that the split-bf16 result can be judged against it
-            try:
-                ops.CONV_IMPL = "f32"
-                alt = engine.IterationRunner(prob, seed=0, sample_offset=offset, use_graph=not args.no_graph)
-                for k in order[:3]:
-                    alt.run(int(k))
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                n_alt = min(steps, 20)
-                for k in order[warm:warm + n_alt]:
-                    alt.run(int(k))
-                torch.cuda.synchronize()
-                alt_ms = (time.perf_counter() - t1) * 1e3 / n_alt
-                out["alt_fp32_mfma"] = {
-                    "ms_per_step": alt_ms, "value": total / (alt_ms * 1e-3 * ITER_PER_RECON), "steps": n_alt,
-                    "note": "IPDM_CONV_IMPL=f32: v_mfma_f32_32x32x2_f32 direct + fp32 Winograd kernels, same graph "
-                            "structure; not the headline",
-                }
-            finally:
-                ops.CONV_IMPL = "bx3"
+        if world == 1 and not args.full and not args.no_alt and ops.split_impl():
+            # the same iteration through the other kernel families, reported beside the headline so that the split result can
+            # be judged against them: the exact-fp32-MFMA kernels (conv_mfma_kernel + fp32 Winograd) and the other split
+            headline_impl = ops.CONV_IMPL
+            notes = {"f32": ("alt_fp32_mfma", "IPDM_CONV_IMPL=f32: v_mfma_f32_32x32x2_f32 direct + fp32 Winograd kernels"),
+                     "bx3": ("alt_bf16x3", "IPDM_CONV_IMPL=bx3: three bf16 pieces, six bf16 MFMAs per product (round 2's default)"),
+                     "hx2": ("alt_f16x2", "IPDM_CONV_IMPL=hx2: two fp16 pieces, three fp16 MFMAs per product")}
+            for impl in ("f32", "bx3", "hx2"):
+                if impl == headline_impl:
+                    continue
+                try:
+                    ops.CONV_IMPL = impl
+                    alt = engine.IterationRunner(prob, seed=0, sample_offset=offset, use_graph=not args.no_graph)
+                    for k in order[:3]:
+                        alt.run(int(k))
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    n_alt = min(steps, 20)
+                    for k in order[warm:warm + n_alt]:
+                        alt.run(int(k))
+                    torch.cuda.synchronize()
+                    alt_ms = (time.perf_counter() - t1) * 1e3 / n_alt
+                    out[notes[impl][0]] = {
+                        "ms_per_step": alt_ms, "value": total / (alt_ms * 1e-3 * ITER_PER_RECON), "steps": n_alt,
+                        "note": notes[impl][1] + ", same graph structure; not the headline",
+                    }
+                    del alt
+                finally:
+                    ops.CONV_IMPL = headline_impl
+        if world == 1 and not args.full and not args.no_alt:
+            out["upfirdn2d"] = upfirdn2d_hbm(dev)
         if world == 1 and not args.full and not args.no_full_batch and total != 105:
             # the WHOLE of BASELINE config 3 (105 posterior samples) on this one GPU: with the driver's N = 2, 4, 8 runs this
             # is the strong-scaling reference point of the 1 -> 8 curve (the headline `value` keeps the per-GPU share).

@@ -737,7 +737,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     }
   }
   const int r_lane = DMA4 ? (2 * (mytile / TX)) * RC4 + 2 * (mytile % TX) + 2 : (2 * (mytile / TX)) * RC + 2 * (mytile % TX);
-  auto read_patch = [&](int kc) {
+  auto read_patch_to = [&](float (&dreg)[16], int kc) {
     if constexpr (POLY) {
       const float* rp = rs + kc * (QN * 4);
 #pragma unroll
@@ -774,6 +774,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       }
     }
   };
+  auto read_patch = [&](int kc) { read_patch_to(dreg, kc); };
   auto store_patch = [&](float* st, int kc) {
     const float(&dd)[16] = dreg;
     float tmp[16];
@@ -797,8 +798,8 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   // f16x2: B^T d B of the patch in dreg -> v (registers); the two channels 2w, 2w+1 of a tile are then split together and
   // stored as packed fp16 pairs, Vs[pos][piece 2][channel pair 8][tile 64] 32-bit words (channel 2c in the low half): the
   // reader's four words per piece ARE its MFMA operand -- the split is done once, by the writer, at 2 VALU per element
-  auto transform = [&](float (&v)[16]) {
-    const float(&dd)[16] = dreg;
+  auto transform = [&](float (&v)[16]) {                      // in place: B^T v B
+    const float(&dd)[16] = v;
     float tmp[16];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -815,10 +816,10 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       v[rr * 4 + 3] = tmp[rr * 4 + 1] - tmp[rr * 4 + 3];
     }
   };
-  auto store_pair = [&](float* st, const float (&va)[16], const float (&vb)[16]) {
+  auto store_pair = [&](float* st, const float (&va)[16], const float (&vb)[16], auto p_lo, auto p_hi) {
     unsigned* vs = reinterpret_cast<unsigned*>(st) + wave * X_TILES + mytile;
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
+    for (int p = decltype(p_lo)::value; p < decltype(p_hi)::value; ++p) {
       unsigned hp, lp;
       split2_pk(va[p], vb[p], hp, lp);
       vs[(p * 2 + 0) * (8 * X_TILES)] = hp;
@@ -829,11 +830,11 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   auto stage_chunk = [&](float* st) {
     if constexpr (HX) {
       float va[16], vb[16];
-      read_patch(2 * wave);
+      read_patch_to(va, 2 * wave);
       transform(va);
-      read_patch(2 * wave + 1);
+      read_patch_to(vb, 2 * wave + 1);
       transform(vb);
-      store_pair(st, va, vb);
+      store_pair(st, va, vb, std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
     } else {
       read_patch(2 * wave);
       store_patch(st, 2 * wave);
@@ -913,6 +914,56 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       const bool a_next = ch + 1 >= n_chunks;
       const int a_chunk = a_next ? next_g.c0 : cur_g.c0 + ch + 1;
       const int a_cot = a_next ? next_g.co_tile : cur_g.co_tile;
+      if constexpr (HX) {
+        // f16x2 chunk.  With three MFMAs per product the matrix work of a chunk (48 MFMAs per wave) no longer covers a DMA
+        // round trip issued a quarter chunk in: the raw patches are read into registers FIRST, the barrier that frees the raw
+        // stage follows at once and the DMA of chunk c+2 is issued right behind it (a whole chunk to land); the transform,
+        // the split and the packed stores of chunk c+1 are dealt from registers over the four MFMA steps.  The A fragments
+        // of position p0+1 are requested before the DMA (vmcnt retires in order: a load issued behind the DMA and consumed in
+        // this chunk would wait for the DMA).
+        uint4 bsh[2][2];
+        float va[16], vb[16];
+        load_A(afr[1], p0 + 1, cur_g.c0 + ch, cur_g.co_tile);
+        read_patch_to(va, 2 * wave);
+        read_patch_to(vb, 2 * wave + 1);
+        load_Bh(bsh[0], cur, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                        // everyone has read the raw stage
+        IPDM_TR(5);
+        issue_dma(dma_chunk);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<4>([&](auto sc) {
+          constexpr int st = decltype(sc)::value;
+          constexpr int pi = st >> 1, tg = st & 1;
+          if constexpr (st < 3) load_Bh(bsh[(st + 1) & 1], cur, (st + 1) >> 1, (st + 1) & 1);
+          if constexpr (st == 0) transform(va);
+          if constexpr (st == 1) transform(vb);
+          if constexpr (st == 2) {
+            store_pair(nxt, va, vb, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+            load_A(afr[0], p0, a_chunk, a_cot);
+          }
+          if constexpr (st == 3) store_pair(nxt, va, vb, std::integral_constant<int, 8>{}, std::integral_constant<int, 16>{});
+          const f16x8 bh = __builtin_bit_cast(f16x8, bsh[st & 1][0]), bl = __builtin_bit_cast(f16x8, bsh[st & 1][1]);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            f32x16 v = acc[pi][c][tg];
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][1]), bh, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][0]), bl, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][0]), bh, v, 0, 0, 0);
+            acc[pi][c][tg] = v;
+          }
+          if constexpr (st < 3) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // next step's operand reads first
+          if constexpr (st == 2) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);    // ... and the fragment requests
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
+            if constexpr (st >= 2) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          IPDM_TR(1 + st);
+        });
+      } else {
       bf16x8 bs[2][3];
       uint4 bsh[2][2];
       float raw[8];
@@ -990,6 +1041,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
           IPDM_TR(5);
         }
       });
+      }
       __builtin_amdgcn_s_waitcnt(0);                          // the DMA has landed
       IPDM_TR(6);
       __syncthreads();

@@ -7,7 +7,7 @@ from inverseproblemwithdiffusionmodel_amd import ops, _lib
 B = 28
 for ci, co, hw in [(128, 128, 128), (256, 256, 64)]:
     x = torch.randn(B, ci, hw, hw, device="cuda"); w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
-    U = ops.conv_wino_bx3_weight(w)
+    U = ops.conv_wino_bx3_weight(w, fmt=os.environ.get('FMT', 'hx2'))
     buf = torch.zeros(1 << 20, dtype=torch.int64, device="cuda")
     for _ in range(3): ops.conv2d_wino_bx3(x, U)
     torch.cuda.synchronize()
@@ -23,6 +23,6 @@ for ci, co, hw in [(128, 128, 128), (256, 256, 64)]:
     tiles = B * hw * hw / px_per_tile * (co // 64)
     per_wg = tiles / t.shape[0]
     nch = ci // 16
-    mfma_bound = 96 * 32
+    mfma_bound = (48 if os.environ.get('FMT', 'hx2') == 'hx2' else 96) * 32
     print(f"{ci}->{co}@{hw}: {ms * 1e3:.0f} us, {t.shape[0]} workgroups x {per_wg:.1f} tiles; cycles/WG median {tot.median():.0f} max {tot.max():.0f}; "
           f"per (tile, chunk) {tot.median() / per_wg / nch:.0f} (MFMA-bound {mfma_bound}); implied clock {tot.max() / ms / 1e6:.2f} GHz")

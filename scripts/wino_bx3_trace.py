@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from inverseproblemwithdiffusionmodel_amd import ops, _lib
 B, ci, co, hw = 28, 128, 128, 128
 x = torch.randn(B, ci, hw, hw, device="cuda"); w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
-U = ops.conv_wino_bx3_weight(w)
+U = ops.conv_wino_bx3_weight(w, fmt=os.environ.get('FMT', 'hx2'))
 nblk = 256                                       # persistent kernel: one workgroup per CU
 buf = torch.zeros(nblk * 4 + nblk * 64, dtype=torch.int64, device="cuda")
 for _ in range(3): ops.conv2d_wino_bx3(x, U)
