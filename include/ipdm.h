@@ -53,10 +53,28 @@ int ipdm_upfirdn2d_f32(const float* in, const float* kernel, float* out,
                        int up_x, int up_y, int down_x, int down_y,
                        int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 
+/* the other storage types of the reference's dispatch (AT_DISPATCH_FLOATING_TYPES_AND_HALF, op/upfirdn2d_kernel.cu:311):
+ * IEEE half (2-byte elements behind the void pointers; fp32 arithmetic, one rounding at the store) and double */
+int ipdm_upfirdn2d_f16(const void* in, const void* kernel, void* out,
+                       int major, int in_h, int in_w, int minor, int kernel_h, int kernel_w,
+                       int up_x, int up_y, int down_x, int down_y,
+                       int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+int ipdm_upfirdn2d_f64(const double* in, const double* kernel, double* out,
+                       int major, int in_h, int in_w, int minor, int kernel_h, int kernel_w,
+                       int up_x, int up_y, int down_x, int down_y,
+                       int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
 /* y[i] = act(x[i] + b[(i / step_b) % size_b]) * scale;  act*10+grad as in the reference kernel:
  * 10/11 linear, 12 zero, 30 leaky-relu(alpha), 31 leaky-relu gradient gated by ref, 32 zero.
  * b == NULL or size_b == 0: no bias.  ref == NULL: treated as zeros. */
 int ipdm_fused_bias_act_f32(const float* x, const float* b, const float* ref, float* y,
+                            int64_t n, int step_b, int size_b, int act, int grad,
+                            float alpha, float scale, void* stream);
+/* half / double storage (op/fused_bias_act_kernel.cu:79 dispatches the same three types) */
+int ipdm_fused_bias_act_f16(const void* x, const void* b, const void* ref, void* y,
+                            int64_t n, int step_b, int size_b, int act, int grad,
+                            float alpha, float scale, void* stream);
+int ipdm_fused_bias_act_f64(const double* x, const double* b, const double* ref, double* y,
                             int64_t n, int step_b, int size_b, int act, int grad,
                             float alpha, float scale, void* stream);
 
@@ -346,7 +364,7 @@ int ipdm_conv2d_wino_bx3_stats_f32(const float* x, const void* U, const float* b
  * product (fp32 accumulation) -- half the matrix-core work and two thirds of the weight bytes of the three-way bf16 split.
  * fp32-faithful (error against float64 at or below the bf16 split's and the exact-fp32 kernel's on the networks' layer
  * shapes) under a RANGE contract: weights are scaled per output channel by a power of two at pack time (the inverse scale
- * rides in the blob); activations must satisfy |x| < 65504, and |x| < 16376 for the Winograd calls -- beyond that the result
+ * rides in the blob); activations must satisfy |x| < 65504 (the Winograd calls pre-scale their input transform to keep that bound) -- beyond that the result
  * is NaN / inf (never a wrong finite number); the bx3 calls keep the whole fp32 exponent range.  Same arguments, semantics
  * and replaced reference interface (torch.nn.Conv2d / Conv3d inside ncsn/models/layers.py:28-60) as their bx3 twins; the
  * shape rules (ipdm_conv_bx3_splitk, ipdm_conv2d_wino_bx3_supported / _splitk / _stats_partials) are shared. */

@@ -24,6 +24,10 @@ SIGNATURES = {
     "ipdm_build_arch": [],
     "ipdm_upfirdn2d_f32": [P, P, P] + [c_int] * 14 + [P],
     "ipdm_fused_bias_act_f32": [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, P],
+    "ipdm_upfirdn2d_f16": [P, P, P] + [c_int] * 14 + [P],
+    "ipdm_upfirdn2d_f64": [P, P, P] + [c_int] * 14 + [P],
+    "ipdm_fused_bias_act_f16": [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, P],
+    "ipdm_fused_bias_act_f64": [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, P],
     "ipdm_fft2c_c64": [P, P, c_int, c_int, c_int, c_int, P, P],
     "ipdm_fft2c_workspace_bytes": [c_int, c_int, c_int],
     "ipdm_sense_forward_c64": [P, P, P, c_int, P, c_int, c_int, c_int, c_int, P],

@@ -34,9 +34,9 @@ __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m
 // six bf16 ones of the three-way bf16 split: half the matrix-core cycles, 4 instead of 6 bytes per weight, 2 instead of
 // 5.5 VALU per split element.  Price: fp16's exponent range.  Weights are scaled per output channel by a power of two
 // at pack time (max |w s| in [2^13, 2^14); the inverse scale rides in the blob and is applied in the epilogue's fma);
-// activations must satisfy |x| < 65504 (Winograd: the 4-term input transform |V| <= 4 max|x|, so |x| < 16376) -- an input
-// beyond that gives inf -> NaN in the output, never a silently wrong finite value; IPDM_CONV_IMPL=bx3 keeps the whole fp32
-// exponent range.  Measured against float64 on the networks' layer shapes the error is at or below the three-way bf16
+// activations must satisfy |x| < 65504 (the Winograd kernels pre-scale their 4-term input transform by 1/4 to keep that same
+// bound) -- an input beyond it gives inf -> NaN in the output, never a silently wrong finite value; IPDM_CONV_IMPL=bx3 keeps
+// the whole fp32 exponent range.  Measured against float64 on the networks' layer shapes the error is at or below the three-way bf16
 // split's and the exact-fp32 MFMA kernel's.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -52,6 +52,22 @@ __device__ __forceinline__ void split2_pk(float v0, float v1, unsigned& hp, unsi
   const f16x2 ll = {(_Float16)r0, (_Float16)r1};
   lp = __builtin_bit_cast(unsigned, ll);
 }
+// the same with a power-of-two pre-scale s (the Winograd kernels: s = 1/4 undoes the growth of the 4-term input transform,
+// so that their range contract is the direct kernels' |x| < 65504; the epilogue's inverse weight scale carries the 4):
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 (f16(v * s), exact scaling), two v_fma_mix_f32 (v * s - f32(h), exact), v_cvt_pk_f16_f32
+__device__ __forceinline__ void split2_pk_scaled(float v0, float v1, float s, unsigned& hp, unsigned& lp) {
+  unsigned h = 0;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(h) : "v"(v0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(v1), "v"(s));
+  hp = h;
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(v0), "v"(s), "v"(h));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(v1), "v"(s), "v"(h));
+  const f16x2 ll = {(_Float16)r0, (_Float16)r1};
+  lp = __builtin_bit_cast(unsigned, ll);
+}
+constexpr float HX_WINO_PRESCALE = 0.25f;
+
 // eight consecutive k values -> the hi and the lo MFMA operand
 __device__ __forceinline__ void split2(const float (&v)[8], uint4& h, uint4& l) {
   split2_pk(v[0], v[1], h.x, l.x);

@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void wino_hx2_scale_kernel(const float* __rest
     int e = 0;
     const float mx = red[0];
     if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &e);       // mx = f * 2^e, f in [0.5, 1)
-    inv_scale[co] = mx > 0.f && mx < INFINITY ? ldexpf(1.f, e - 14) : 1.f;   // scale 2^(14 - e): mx * scale in [2^13, 2^14)
+    // weight scale 2^(14 - e): mx * scale in [2^13, 2^14); the stored inverse also undoes the kernels' input pre-scale
+    inv_scale[co] = (mx > 0.f && mx < INFINITY ? ldexpf(1.f, e - 14) : 1.f) / HX_WINO_PRESCALE;
   }
 }
 
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void wino_hx2_weight_kernel(const float* __res
     const int p = (int)(rest / ((int64_t)n_ct * n_cc));
     const int co = ct * 32 + r, ci = cc * 16 + 8 * h + q;
     float v = 0.f;
-    if (co < Cout && ci < Cin) v = wino_U(w + ((size_t)co * Cin + ci) * 9, p) * (1.f / inv_scale[co]);
+    if (co < Cout && ci < Cin) v = wino_U(w + ((size_t)co * Cin + ci) * 9, p) * (1.f / (inv_scale[co] * HX_WINO_PRESCALE));
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)(v - (float)hi);
     const int64_t base = rest * 2 * 512 + h * 256 + r * 8 + q;
@@ -224,8 +225,9 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
                              tmp[r * 4 + 1] - tmp[r * 4 + 3]};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const _Float16 hi = (_Float16)v4[c];
-          const _Float16 lo = (_Float16)(v4[c] - (float)hi);
+          const float vsc = v4[c] * HX_WINO_PRESCALE;         // exact; undone by the inverse weight scale
+          const _Float16 hi = (_Float16)vsc;
+          const _Float16 lo = (_Float16)(vsc - (float)hi);
           vs[((r * 4 + c) * 2 + 0) * (X_KC * X_TILES)] = hi;
           vs[((r * 4 + c) * 2 + 1) * (X_KC * X_TILES)] = lo;
         }
@@ -821,7 +823,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
 #pragma unroll
     for (int p = decltype(p_lo)::value; p < decltype(p_hi)::value; ++p) {
       unsigned hp, lp;
-      split2_pk(va[p], vb[p], hp, lp);
+      split2_pk_scaled(va[p], vb[p], HX_WINO_PRESCALE, hp, lp);
       vs[(p * 2 + 0) * (8 * X_TILES)] = hp;
       vs[(p * 2 + 1) * (8 * X_TILES)] = lp;
     }

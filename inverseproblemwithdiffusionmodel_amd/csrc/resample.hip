@@ -13,6 +13,7 @@
 // op/fused_bias_act_kernel.cu:19-49 of the reference.
 #include "ipdm_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -23,15 +24,22 @@ __host__ __device__ __forceinline__ int floor_div_i(int a, int b) {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int UP, int DOWN, int K, int TOH, int TOW>
+// T: storage type (float, _Float16, double -- the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+// op/upfirdn2d_kernel.cu:311); A: accumulator (float for half / float: one rounding at the store instead of the reference's
+// per-tap half arithmetic; double for double)
+template <typename T> struct AccOf { typedef float type; };
+template <> struct AccOf<double> { typedef double type; };
+
+template <typename T, int UP, int DOWN, int K, int TOH, int TOW>
 __global__ __launch_bounds__(256) void upfirdn2d_tiled_kernel(
-    const float* __restrict__ in, const float* __restrict__ kernel, float* __restrict__ out,
+    const T* __restrict__ in, const T* __restrict__ kernel, T* __restrict__ out,
     int in_h, int in_w, int out_h, int out_w, int kernel_h, int kernel_w, int pad_x0, int pad_y0) {
+  typedef typename AccOf<T>::type A;
   constexpr int TIH = ((TOH - 1) * DOWN + K - 1) / UP + 2;
   constexpr int TIW = ((TOW - 1) * DOWN + K - 1) / UP + 2;
   constexpr int NT = (K + UP - 1) / UP;     // taps per axis that can hit a real sample
-  __shared__ float sk[K][K];
-  __shared__ float sx[TIH][TIW + 1];
+  __shared__ A sk[K][K];
+  __shared__ A sx[TIH][TIW + 1];
 
   const int plane = blockIdx.x;
   const int oy0 = blockIdx.y * TOH;
@@ -41,24 +49,24 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled_kernel(
   // flipped taps, zero-extended to K x K
   if (tid < K * K) {
     int ky = tid / K, kx = tid % K;
-    float v = 0.f;
-    if (ky < kernel_h && kx < kernel_w) v = kernel[(kernel_h - 1 - ky) * kernel_w + (kernel_w - 1 - kx)];
+    A v = 0;
+    if (ky < kernel_h && kx < kernel_w) v = (A)kernel[(kernel_h - 1 - ky) * kernel_w + (kernel_w - 1 - kx)];
     sk[ky][kx] = v;
   }
   // first input row / column any output of this tile touches
   const int tin_y0 = floor_div_i(oy0 * DOWN + UP - 1 - pad_y0, UP);
   const int tin_x0 = floor_div_i(ox0 * DOWN + UP - 1 - pad_x0, UP);
-  const float* src = in + (size_t)plane * in_h * in_w;
+  const T* src = in + (size_t)plane * in_h * in_w;
   for (int i = tid; i < TIH * TIW; i += 256) {
     int r = i / TIW, c = i - r * TIW;
     int gy = tin_y0 + r, gx = tin_x0 + c;
-    float v = 0.f;
-    if (gy >= 0 && gy < in_h && gx >= 0 && gx < in_w) v = src[(size_t)gy * in_w + gx];
+    A v = 0;
+    if (gy >= 0 && gy < in_h && gx >= 0 && gx < in_w) v = (A)src[(size_t)gy * in_w + gx];
     sx[r][c] = v;
   }
   __syncthreads();
 
-  float* dst = out + (size_t)plane * out_h * out_w;
+  T* dst = out + (size_t)plane * out_h * out_w;
   for (int i = tid; i < TOH * TOW; i += 256) {
     int ty = i / TOW, tx = i - ty * TOW;
     int oy = oy0 + ty, ox = ox0 + tx;
@@ -68,7 +76,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled_kernel(
     int jy0 = fy * UP - (oy * DOWN - pad_y0);                  // its tap index in the flipped kernel
     int jx0 = fx * UP - (ox * DOWN - pad_x0);
     int ry = fy - tin_y0, rx = fx - tin_x0;
-    float acc = 0.f;
+    A acc = 0;
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
       int jy = jy0 + a * UP;
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled_kernel(
         acc += sx[ry + a][rx + b] * sk[jy][jx];
       }
     }
-    dst[(size_t)oy * out_w + ox] = acc;
+    dst[(size_t)oy * out_w + ox] = (T)acc;
   }
 }
 
@@ -241,9 +249,10 @@ struct UpfirdnParams {
   int major, in_h, in_w, minor, kernel_h, kernel_w, out_h, out_w;
 };
 
-__global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(const float* __restrict__ in,
-                                                                const float* __restrict__ kernel,
-                                                                float* __restrict__ out, UpfirdnParams p) {
+template <typename T>
+__global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(const T* __restrict__ in, const T* __restrict__ kernel,
+                                                                T* __restrict__ out, UpfirdnParams p) {
+  typedef typename AccOf<T>::type A;
   const int64_t total = (int64_t)p.major * p.out_h * p.out_w * p.minor;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(const float* __r
     int fx = floor_div_i(mid_x, p.up_x);
     int kx0 = mid_x + p.kernel_w - (fx + 1) * p.up_x;
 
-    float acc = 0.f;
+    A acc = 0;
     for (int a = 0, ky = ky0; ky >= 0; ++a, ky -= p.up_y) {
       int gy = fy + a;
       if (gy < 0 || ky >= p.kernel_h) continue;
@@ -270,17 +279,17 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(const float* __r
         int gx = fx + b;
         if (gx < 0 || kx >= p.kernel_w) continue;
         if (gx >= p.in_w) break;
-        acc += in[(((size_t)major * p.in_h + gy) * p.in_w + gx) * p.minor + mi] * kernel[ky * p.kernel_w + kx];
+        acc += (A)in[(((size_t)major * p.in_h + gy) * p.in_w + gx) * p.minor + mi] * (A)kernel[ky * p.kernel_w + kx];
       }
     }
-    out[idx] = acc;
+    out[idx] = (T)acc;
   }
 }
 
-template <int UP, int DOWN, int K, int TOH, int TOW>
-int launch_tiled(const float* in, const float* kernel, float* out, const UpfirdnParams& p, hipStream_t s) {
+template <typename T, int UP, int DOWN, int K, int TOH, int TOW>
+int launch_tiled(const T* in, const T* kernel, T* out, const UpfirdnParams& p, hipStream_t s) {
   dim3 grid(p.major, (p.out_h + TOH - 1) / TOH, (p.out_w + TOW - 1) / TOW);
-  hipLaunchKernelGGL((upfirdn2d_tiled_kernel<UP, DOWN, K, TOH, TOW>), grid, dim3(256), 0, s, in, kernel, out,
+  hipLaunchKernelGGL((upfirdn2d_tiled_kernel<T, UP, DOWN, K, TOH, TOW>), grid, dim3(256), 0, s, in, kernel, out,
                      p.in_h, p.in_w, p.out_h, p.out_w, p.kernel_h, p.kernel_w, p.pad_x0, p.pad_y0);
   return ipdm_launch_status();
 }
@@ -307,6 +316,28 @@ int launch_stream(const float* in, const float* kernel, float* out, const Upfird
 }
 
 // ---------------------------------------------------------------------------------------------
+// scalar form for the other storage types of the reference's dispatch (half, double; op/fused_bias_act_kernel.cu:79);
+// arithmetic in float (half) / double
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_any_kernel(const T* __restrict__ x, const T* __restrict__ b,
+                                                           const T* __restrict__ ref, T* __restrict__ y, int64_t n,
+                                                           int step_b, int size_b, int code, float alpha, float scale) {
+  typedef typename AccOf<T>::type A;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    A t = (A)x[i];
+    if (b) t += (A)b[(i / step_b) % size_b];
+    A o;
+    switch (code) {
+      case 30: o = t > (A)0 ? t : t * (A)alpha; break;
+      case 31: o = (ref ? (A)ref[i] : (A)0) > (A)0 ? t : t * (A)alpha; break;
+      case 12:
+      case 32: o = (A)0; break;
+      default: o = t; break;
+    }
+    y[i] = (T)(o * (A)scale);
+  }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b,
                                                        const float* __restrict__ ref, float* __restrict__ y,
@@ -351,9 +382,10 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int ipdm_upfirdn2d_f32(const float* in, const float* kernel, float* out, int major, int in_h, int in_w,
-                                  int minor, int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y,
-                                  int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
+template <typename T>
+static int upfirdn2d_entry(const T* in, const T* kernel, T* out, int major, int in_h, int in_w, int minor, int kernel_h,
+                           int kernel_w, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                           int pad_y1, void* stream) {
   IPDM_REQUIRE(in && kernel && out);
   IPDM_REQUIRE(major >= 0 && in_h > 0 && in_w > 0 && minor > 0 && kernel_h > 0 && kernel_w > 0);
   IPDM_REQUIRE(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0);
@@ -366,22 +398,72 @@ extern "C" int ipdm_upfirdn2d_f32(const float* in, const float* kernel, float* o
   if (major == 0) return IPDM_OK;
   hipStream_t s = ipdm_stream(stream);
   const bool sq = up_x == up_y && down_x == down_y && minor == 1 && kernel_h <= 4 && kernel_w <= 4;
-  // the NCSN++ resampling calls (models/up_or_down_sampling.py:191-257: down2 pad (1,1), up2 pad (2,1) with [1,3,3,1] taps)
-  // on float4-shaped rows -> register-streaming kernel
-  const bool vec_ok = sq && in_w % 4 == 0 && p.out_w % 4 == 0 && pad_x0 == pad_y0 &&
-                      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-  int rc = IPDM_EUNSUPPORTED;
-  // (the up-sampler writes 4x what it reads: one float4 of outputs per thread and row keeps every store instruction a
-  //  contiguous KiB per wave -- 4.9 vs 3.6 TB/s at 128^2 -> 256^2 against two float4s per thread)
-  if (vec_ok && up_x == 1 && down_x == 2 && pad_x0 == 1) rc = launch_stream<1, 2, 1, 1, 4>(in, kernel, out, p, s);
-  if (vec_ok && up_x == 2 && down_x == 1 && pad_x0 == 2) rc = launch_stream<2, 1, 2, 2, 4>(in, kernel, out, p, s);
-  if (rc != IPDM_EUNSUPPORTED) return rc;
-  if (sq && up_x == 1 && down_x == 2) return launch_tiled<1, 2, 4, 16, 64>(in, kernel, out, p, s);
-  if (sq && up_x == 2 && down_x == 1) return launch_tiled<2, 1, 4, 32, 64>(in, kernel, out, p, s);
-  if (sq && up_x == 1 && down_x == 1) return launch_tiled<1, 1, 4, 32, 64>(in, kernel, out, p, s);
+  if constexpr (std::is_same<T, float>::value) {
+    // the NCSN++ resampling calls (models/up_or_down_sampling.py:191-257: down2 pad (1,1), up2 pad (2,1) with [1,3,3,1]
+    // taps) on float4-shaped rows -> register-streaming kernel
+    const bool vec_ok = sq && in_w % 4 == 0 && p.out_w % 4 == 0 && pad_x0 == pad_y0 &&
+                        ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    int rc = IPDM_EUNSUPPORTED;
+    // (the up-sampler writes 4x what it reads: one float4 of outputs per thread and row keeps every store instruction a
+    //  contiguous KiB per wave -- 4.9 vs 3.6 TB/s at 128^2 -> 256^2 against two float4s per thread)
+    if (vec_ok && up_x == 1 && down_x == 2 && pad_x0 == 1) rc = launch_stream<1, 2, 1, 1, 4>(in, kernel, out, p, s);
+    if (vec_ok && up_x == 2 && down_x == 1 && pad_x0 == 2) rc = launch_stream<2, 1, 2, 2, 4>(in, kernel, out, p, s);
+    if (rc != IPDM_EUNSUPPORTED) return rc;
+  }
+  if (sq && up_x == 1 && down_x == 2) return launch_tiled<T, 1, 2, 4, 16, 64>(in, kernel, out, p, s);
+  if (sq && up_x == 2 && down_x == 1) return launch_tiled<T, 2, 1, 4, 32, 64>(in, kernel, out, p, s);
+  if (sq && up_x == 1 && down_x == 1) return launch_tiled<T, 1, 1, 4, 32, 64>(in, kernel, out, p, s);
   const int64_t total = (int64_t)major * p.out_h * p.out_w * minor;
-  hipLaunchKernelGGL(upfirdn2d_generic_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, s, in, kernel, out, p);
+  hipLaunchKernelGGL(upfirdn2d_generic_kernel<T>, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, s, in, kernel, out, p);
   return ipdm_launch_status();
+}
+
+extern "C" int ipdm_upfirdn2d_f32(const float* in, const float* kernel, float* out, int major, int in_h, int in_w,
+                                  int minor, int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y,
+                                  int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
+  return upfirdn2d_entry<float>(in, kernel, out, major, in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y,
+                                pad_x0, pad_x1, pad_y0, pad_y1, stream);
+}
+
+/* IEEE half storage (in / kernel / out: 2-byte elements), fp32 arithmetic, one rounding at the store */
+extern "C" int ipdm_upfirdn2d_f16(const void* in, const void* kernel, void* out, int major, int in_h, int in_w,
+                                  int minor, int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y,
+                                  int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
+  return upfirdn2d_entry<_Float16>(static_cast<const _Float16*>(in), static_cast<const _Float16*>(kernel),
+                                   static_cast<_Float16*>(out), major, in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y,
+                                   down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, stream);
+}
+
+extern "C" int ipdm_upfirdn2d_f64(const double* in, const double* kernel, double* out, int major, int in_h, int in_w,
+                                  int minor, int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y,
+                                  int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
+  return upfirdn2d_entry<double>(in, kernel, out, major, in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y,
+                                 pad_x0, pad_x1, pad_y0, pad_y1, stream);
+}
+
+template <typename T>
+static int bias_act_any_entry(const T* x, const T* b, const T* ref, T* y, int64_t n, int step_b, int size_b, int act, int grad,
+                              float alpha, float scale, void* stream) {
+  IPDM_REQUIRE(n >= 0);
+  if (n == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && y);
+  if (size_b <= 0) b = nullptr;
+  if (b) IPDM_REQUIRE(step_b > 0);
+  hipLaunchKernelGGL(bias_act_any_kernel<T>, dim3(ipdm_ew_grid(n, 256)), dim3(256), 0, ipdm_stream(stream), x, b, ref, y, n,
+                     step_b, size_b, act * 10 + grad, alpha, scale);
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_fused_bias_act_f16(const void* x, const void* b, const void* ref, void* y, int64_t n, int step_b,
+                                       int size_b, int act, int grad, float alpha, float scale, void* stream) {
+  return bias_act_any_entry<_Float16>(static_cast<const _Float16*>(x), static_cast<const _Float16*>(b),
+                                      static_cast<const _Float16*>(ref), static_cast<_Float16*>(y), n, step_b, size_b, act,
+                                      grad, alpha, scale, stream);
+}
+
+extern "C" int ipdm_fused_bias_act_f64(const double* x, const double* b, const double* ref, double* y, int64_t n, int step_b,
+                                       int size_b, int act, int grad, float alpha, float scale, void* stream) {
+  return bias_act_any_entry<double>(x, b, ref, y, n, step_b, size_b, act, grad, alpha, scale, stream);
 }
 
 extern "C" int ipdm_fused_bias_act_f32(const float* x, const float* b, const float* ref, float* y, int64_t n,

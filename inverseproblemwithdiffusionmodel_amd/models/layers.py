@@ -47,18 +47,21 @@ class Conv(ops.PackedWeightMixin, nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_planes)) if bias else None
         self._cache = ops.PackedWeightCache()
 
+    # score_sde networks feed raw (un-normalised) skip / progressive streams into convolutions: ops.impl_unbounded()
     def packed(self):
-        return self._cache.get(self.weight, "direct_" + ops.CONV_IMPL, ops.conv_weight)
+        impl = ops.impl_unbounded()
+        return self._cache.get(self.weight, "direct_" + impl, lambda w: ops.conv_weight(w, impl))
 
     def packed_wino(self):
-        return self._cache.get(self.weight, "wino_" + ops.CONV_IMPL, ops.conv_wino_split_weight)
+        impl = ops.impl_unbounded()
+        return self._cache.get(self.weight, "wino_" + impl, lambda w: ops.conv_wino_split_weight(w, impl))
 
     def forward(self, x, residual=None):
         bias = None if self.bias is None else self.bias.data
         if (self.kernel_size == 3 and self.dilation == 1 and residual is None and min(self.in_planes, self.out_planes) <= 3
                 and ops.conv3x3_thin_ok(self.in_planes, self.out_planes, x.shape[2], x.shape[3])):
             return ops.conv3x3_thin(x, self.weight.data, bias)         # first / last layer: streaming kernels
-        if (ops.split_impl() and self.kernel_size == 3
+        if (ops.impl_unbounded() in ops.SPLIT_IMPLS and self.kernel_size == 3
                 and ops.wino_bx3_pays(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation)):
             return ops.conv2d_wino_bx3(x, self.packed_wino(), bias, residual, dilation=self.dilation)
         return ops.conv2d(x, self.packed(), bias, residual=residual, dilation=self.dilation)

@@ -74,7 +74,7 @@ def conv_downsample_2d(x, w, k=None, factor=2, gain=1, packed=None, bias=None):
     fir = _fir(k, gain, x.device)
     p = (fir.shape[0] - factor) + (convW - 1)
     x = upfirdn2d(x, fir, pad=((p + 1) // 2, p // 2))
-    return ops.conv2d_stride2_valid(x, ops.conv_weight(w) if packed is None else packed, bias, convW)
+    return ops.conv2d_stride2_valid(x, ops.conv_weight(w, ops.impl_unbounded()) if packed is None else packed, bias, convW)
 
 
 class Conv2d(ops.PackedWeightMixin, nn.Module):
@@ -96,7 +96,8 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
     def forward(self, x):
         if self.up:
             return upsample_conv_2d(x, self.weight, k=self.resample_kernel)
-        packed = self._cache.get(self.weight, "direct_" + ops.CONV_IMPL, ops.conv_weight)
+        impl = ops.impl_unbounded()
+        packed = self._cache.get(self.weight, "direct_" + impl, lambda w: ops.conv_weight(w, impl))
         if self.down:                   # the bias rides in the convolution epilogue (= x + bias.reshape(1, -1, 1, 1) afterwards)
             return conv_downsample_2d(x, self.weight, k=self.resample_kernel, packed=packed,
                                       bias=self.bias.data if self.use_bias else None)

@@ -13,6 +13,6 @@ def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
         raise RuntimeError("upfirdn2d: expected a GPU tensor (this build has no CPU fallback; the reference's "
                            "upfirdn2d_native lives in oracle/resample.py for tests only)")
     batch, channel, in_h, in_w = input.shape
-    out = ops.upfirdn2d_raw(input.reshape(-1, in_h, in_w, 1), kernel.to(input.device, torch.float32),
+    out = ops.upfirdn2d_raw(input.reshape(-1, in_h, in_w, 1), kernel.to(input.device),
                             up, up, down, down, pad[0], pad[1], pad[0], pad[1])
     return out.view(-1, channel, out.shape[1], out.shape[2])

@@ -52,29 +52,43 @@ def _c64_as_f32(t):
 
 
 # ---- StyleGAN2 ops -----------------------------------------------------------------------------
+_FLOAT_SUFFIX = {torch.float32: "f32", torch.float16: "f16", torch.float64: "f64"}   # the reference's dispatch types
+
+
+def _float_suffix(t, what):
+    try:
+        return _FLOAT_SUFFIX[t.dtype]
+    except KeyError:
+        raise TypeError(f"ipdm {what}: dtype {t.dtype} (float32 / float16 / float64, as the reference's "
+                        "AT_DISPATCH_FLOATING_TYPES_AND_HALF)") from None
+
+
 def upfirdn2d_raw(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
-    """x [major, in_h, in_w, minor] -> [major, out_h, out_w, minor] (the reference extension's signature)."""
-    x = _gpu(x, torch.float32, "input")
-    kernel = _gpu(kernel, torch.float32, "kernel")
+    """x [major, in_h, in_w, minor] -> [major, out_h, out_w, minor] (the reference extension's signature);
+    float32 (the tuned kernels), float16 or float64 storage; the taps are cast to the input's dtype"""
+    sfx = _float_suffix(x, "upfirdn2d")
+    x = _gpu(x, x.dtype, "input")
+    kernel = _gpu(kernel.to(x.dtype), x.dtype, "kernel")
     major, in_h, in_w, minor = x.shape
     kh, kw = kernel.shape
     out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) // down_y + 1
     out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) // down_x + 1
-    out = torch.empty((major, out_h, out_w, minor), dtype=torch.float32, device=x.device)
-    call("ipdm_upfirdn2d_f32", _ptr(x), _ptr(kernel), _ptr(out), major, in_h, in_w, minor, kh, kw,
+    out = torch.empty((major, out_h, out_w, minor), dtype=x.dtype, device=x.device)
+    call(f"ipdm_upfirdn2d_{sfx}", _ptr(x), _ptr(kernel), _ptr(out), major, in_h, in_w, minor, kh, kw,
          up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, _stream())
     return out
 
 
 def fused_bias_act_raw(x, bias, ref, act, grad, alpha, scale):
-    x = _gpu(x, torch.float32, "input")
-    bias = None if bias is None or bias.numel() == 0 else _gpu(bias, torch.float32, "bias")
-    ref = None if ref is None or ref.numel() == 0 else _gpu(ref, torch.float32, "refer")
+    sfx = _float_suffix(x, "fused_bias_act")
+    x = _gpu(x, x.dtype, "input")
+    bias = None if bias is None or bias.numel() == 0 else _gpu(bias.to(x.dtype), x.dtype, "bias")
+    ref = None if ref is None or ref.numel() == 0 else _gpu(ref, x.dtype, "refer")
     step_b = 1
     for s in x.shape[2:]:
         step_b *= s
     y = torch.empty_like(x)
-    call("ipdm_fused_bias_act_f32", _ptr(x), _ptr(bias), _ptr(ref), _ptr(y), x.numel(), step_b,
+    call(f"ipdm_fused_bias_act_{sfx}", _ptr(x), _ptr(bias), _ptr(ref), _ptr(y), x.numel(), step_b,
          0 if bias is None else bias.numel(), act, grad, float(alpha), float(scale), _stream())
     return y
 
@@ -690,7 +704,7 @@ def conv3x3_thin(x, weight, bias=None, coef=None):
 # ---- fp32 convolution on the 16-bit matrix cores (exactly split operands) ---------------------------------------
 # Which kernel family the modules use (conv_weight()):
 #   "hx2" (default): operands as two fp16 pieces, three fp16 MFMAs per product (csrc/conv_kernel.h) -- fp32-faithful
-#                    for |activation| < 16376, NaN (never a wrong finite value) beyond
+#                    for |activation| < 65504, NaN (never a wrong finite value) beyond
 #   "bx3":           operands as three bf16 pieces, six bf16 MFMAs per product -- the whole fp32 exponent range
 #   "f32":           the fp32-MFMA direct kernel + fp32 Winograd (conv.hip / conv_wino.hip)
 CONV_IMPL = os.environ.get("IPDM_CONV_IMPL", "hx2")
@@ -702,6 +716,18 @@ if CONV_IMPL not in SPLIT_IMPLS + ("f32",):
 def split_impl():
     """True when the modules run the split-operand kernels (conv_bx3.hip / conv_wino_bx3.hip)"""
     return CONV_IMPL in SPLIT_IMPLS
+
+
+def impl_unbounded():
+    """kernel family for networks whose convolution inputs are NOT bounded by a per-plane normalisation (NCSN++: GroupNorm'ed
+    blocks but raw progressive / skip streams -- 1.7e5 in the full-size golden forward g22): the f16x2 family's range
+    contract (|x| < 65504) does not hold there, so "hx2" is replaced by "bx3" (IPDM_CONV_IMPL_UNBOUNDED overrides)."""
+    env = os.environ.get("IPDM_CONV_IMPL_UNBOUNDED")
+    if env:
+        if env not in SPLIT_IMPLS + ("f32",):
+            raise ValueError(f"IPDM_CONV_IMPL_UNBOUNDED={env!r}")
+        return env
+    return "bx3" if CONV_IMPL == "hx2" else CONV_IMPL
 
 
 class PackedWeightCache:
@@ -736,9 +762,10 @@ class PackedWeightMixin:
         return super()._load_from_state_dict(*args, **kwargs)
 
 
-def conv_weight(w):
-    """pack a convolution weight for the selected kernel family; pass the result to conv2d / conv3d"""
-    return conv_bx3_weight(w, fmt=CONV_IMPL) if split_impl() else conv_pack_weight(w)
+def conv_weight(w, impl=None):
+    """pack a convolution weight for the selected kernel family (impl: override CONV_IMPL); pass the result to conv2d / conv3d"""
+    impl = CONV_IMPL if impl is None else impl
+    return conv_bx3_weight(w, fmt=impl) if impl in SPLIT_IMPLS else conv_pack_weight(w)
 
 
 class PackedBx3:
@@ -836,9 +863,10 @@ def conv_wino_hx2_weight(w):
     return conv_wino_bx3_weight(w, fmt="hx2")
 
 
-def conv_wino_split_weight(w):
+def conv_wino_split_weight(w, impl=None):
     """Winograd-domain weights for the selected split family (CONV_IMPL = "hx2" / "bx3")"""
-    return conv_wino_bx3_weight(w, fmt=CONV_IMPL if split_impl() else "bx3")
+    impl = CONV_IMPL if impl is None else impl
+    return conv_wino_bx3_weight(w, fmt=impl if impl in SPLIT_IMPLS else "bx3")
 
 
 def conv_wino_bx3_supported(Cin, Cout, H, W, dilation=1):
