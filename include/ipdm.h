@@ -439,6 +439,13 @@ int ipdm_nrmse_f32(const float* img, const float* ref, double* out, int n_images
 int ipdm_ssim_f32(const float* img, const float* ref, double* out, int n_images, int H, int W, int ref_broadcast,
                   double data_range, void* stream);
 
+/* Total-variation baseline (reference: scripts/acdc_SENSE_TV.py:76-83 + ncsn/models/MAP_optimizers.py:26-52 MAPModel with
+ * kornia.losses.TotalVariation): x, g complex64 [n_images][H][W] (interleaved re/im).
+ * ipdm_tv_c64: out[b] = sum |x[i+1,j]-x[i,j]| + sum |x[i,j+1]-x[i,j]| (float64);
+ * ipdm_tv_grad_c64: the gradient autograd gives for the complex parameter (unit difference vectors, 0 at a zero difference). */
+int ipdm_tv_c64(const float* x, double* out, int n_images, int H, int W, void* stream);
+int ipdm_tv_grad_c64(const float* x, float* g, int n_images, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,6 +104,8 @@ SIGNATURES = {
     "ipdm_axpy_sched_f32": [P, P, P, c_int64, P, c_float, c_int64, P],
     "ipdm_magnitude_c64": [P, P, c_int64, P],
     "ipdm_posterior_moments_c64": [P, P, c_int, c_int64, P],
+    "ipdm_tv_c64": [P, P, c_int, c_int, c_int, P],
+    "ipdm_tv_grad_c64": [P, P, c_int, c_int, c_int, P],
     "ipdm_nrmse_f32": [P, P, P, c_int, c_int64, c_int, P],
     "ipdm_ssim_f32": [P, P, P, c_int, c_int, c_int, c_int, ctypes.c_double, P],
 }

@@ -364,7 +364,9 @@ class ALD2DTime(ALDOptimizer):
     TV), and the SENSE L2Penalty proximal on every frame.
 
     x_mod_shape: (B, T, C, H, W); measurement: (num_sens, B, T, C, H, W).
-    Extra optional call kwargs: noise_fn(like) (injected noise; default Philox), seed, verbose, n_levels/start_level.
+    Extra optional call kwargs: noise_fn(like) (injected noise; default Philox), seed, sample_offset (first global sample
+    id of this process' block: sharded runs), verbose, n_levels/start_level.  `if_random_shift` draws ONE host-side
+    np.random shift per step for the whole batch (:472): ranks of a sharded run seed numpy identically and stay in step.
     The reference's `_screenshot` PNG dumps are no-ops here."""
 
     def __init__(self, proximal: Proximal, scorenet_T, sigmas_T, *args, **kwargs):
@@ -388,8 +390,11 @@ class ALD2DTime(ALDOptimizer):
         fn = kwargs.get("noise_fn")
         if fn is not None:
             return fn(like).to(like.device)
-        return ops.philox_normal(tuple(like.shape), like.device, seed=kwargs.get("seed", 0), step_id=self._it,
-                                 plane=plane)
+        # rows of `like` per posterior sample (T frames in the spatial step, patches in the temporal one): the Philox
+        # sample id is global, so a sample's noise does not depend on how the batch is sharded over ranks
+        per = like.shape[0] // max(self.measurement.shape[1], 1)
+        return ops.philox_normal(tuple(like.shape), like.device, seed=kwargs.get("seed", 0),
+                                 sample_offset=kwargs.get("sample_offset", 0) * per, step_id=self._it, plane=plane)
 
     @torch.no_grad()
     def __call__(self, **kwargs):

@@ -1,5 +1,5 @@
-"""MAP baselines on the gfx950 kernels (mirror of the reference's ``ncsn/models/MAP_optimizers.py``: ``MAPOptimizer``
-:55-116 and its aliases ``Inpainting`` :119, ``SENSEMAP`` :123 -- SURVEY.md 8f rank 2).
+"""MAP baselines on the gfx950 kernels (mirror of the reference's ``ncsn/models/MAP_optimizers.py``: ``MAPModel`` :26-52
+(the TV baseline), ``MAPOptimizer`` :55-116 and its aliases ``Inpainting`` :119, ``SENSEMAP`` :123 -- SURVEY.md 8f rank 2).
 
 Same constructor and call as the reference: ``SENSEMAP(x_init, measurement, scorenet, linear_tfm, lamda, config,
 logger, device=None, opt_class=None, opt_params=None)``; ``opt()`` runs ``config.MAP.n_iters`` iterations of
@@ -15,6 +15,68 @@ every n_iters // 50 iterations as the reference); ``UndersamplingFourier`` (magn
 import torch
 
 from ... import ops
+
+
+class TotalVariation:
+    """kornia.losses.TotalVariation as the reference's TV baseline uses it (scripts/acdc_SENSE_TV.py:76): sum of the moduli
+    of the vertical and horizontal first differences, one value per image; value and gradient are HIP kernels (tv.hip)"""
+
+    def __call__(self, x):
+        v = ops.tv_value(x.to(torch.complex64).contiguous())
+        return v.reshape(x.shape[:-2])
+
+    def grad(self, x):
+        return ops.tv_grad(x.to(torch.complex64).contiguous())
+
+
+class MAPModel:
+    """The regularised least-squares baseline (reference ncsn/models/MAP_optimizers.py:26-52 MAPModel, trained by
+    helpers/pl_helpers.py:402-442 TrainMAPModel: Adam(lr) on the complex image X initialised with A^H S, one step per epoch):
+        loss = |A X - S|^2 / 2 + reg_weight * reg(X)
+    `reg` needs `__call__(X)` and `grad(X)` (TotalVariation above).  fit(num_epochs, lr) is the training loop (no Lightning:
+    the closed-form data gradient A^H(A X - S) is the SENSE proximal kernel with unit coefficient, the update
+    ipdm_adam_ascent_f32 on the planar (real, imaginary) state -- torch's Adam treats a complex parameter the same way)."""
+
+    def __init__(self, S, lin_tfm, reg, reg_weight, device=None):
+        self.device = torch.device("cuda") if device is None else device
+        self.S = S.to(self.device).to(torch.complex64).contiguous()
+        self.lin_tfm = lin_tfm
+        self.X = lin_tfm.conj_op(self.S).to(torch.complex64).contiguous()
+        self.reg, self.reg_weight = reg, reg_weight
+
+    @torch.no_grad()
+    def forward(self):
+        AX = self.lin_tfm(self.X)
+        data_loss = (torch.abs(AX - self.S) ** 2).sum() / 2
+        reg_loss = self.reg(self.X).sum()
+        return data_loss, reg_loss, data_loss + self.reg_weight * reg_loss
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def fit(self, num_epochs, lr, betas=(0.9, 0.999), eps=1e-8, log_fn=None):
+        tfm, dev = self.lin_tfm, self.device
+        B, H, W = self.X.shape[0], self.X.shape[-2], self.X.shape[-1]
+        x = torch.cat([self.X.real, self.X.imag], dim=0).contiguous().float()        # planar state (2B, 1, H, W)
+        sens, mask = tfm.sens_f32(dev), tfm.mask_u8(dev)
+        m, v = torch.zeros_like(x), torch.zeros_like(x)
+        px = torch.empty_like(x)
+        work = ops.sense_workspace(B, sens.shape[0], H, W, dev)
+        for it in range(num_epochs):
+            # x - A^H(A x - S): the L2 proximal kernel with unit coefficient; minus x = the descent direction of the data term
+            ops.sense_l2prox(x[:B], x[B:], self.S, sens, mask, 1.0, out_re=px[:B], out_im=px[B:], work=work)
+            g = ops.axpby(px, x, 1.0, -1.0)
+            gr = self.reg.grad(torch.complex(x[:B], x[B:]))
+            g = ops.axpby(g, torch.cat([gr.real, gr.imag], dim=0).contiguous(), 1.0, -float(self.reg_weight))
+            ops.adam_ascent(x, g, m, v, lr, it + 1, betas=betas, eps=eps)
+            if log_fn is not None:
+                self.X = torch.complex(x[:B], x[B:])
+                log_fn(it, *self.forward())
+        self.X = torch.complex(x[:B], x[B:])
+        return self.get_reconstruction()
+
+    def get_reconstruction(self):
+        return self.X.detach().cpu()
 
 
 class MAPOptimizer(object):

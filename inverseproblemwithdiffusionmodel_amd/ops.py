@@ -351,6 +351,25 @@ def posterior_moment_planes(samples):
     return planes
 
 
+def tv_value(x):
+    """x (n, ..., H, W) complex64 -> (n',) float64 total variation per image (n' = all leading dims flattened)"""
+    x = _gpu(x, torch.complex64, "x")
+    H, W = x.shape[-2:]
+    n = x.numel() // (H * W)
+    out = torch.empty(n, dtype=torch.float64, device=x.device)
+    call("ipdm_tv_c64", _ptr(x), _ptr(out), n, H, W, _stream())
+    return out
+
+
+def tv_grad(x):
+    """gradient of sum-of-moduli total variation w.r.t. the complex image (torch autograd's convention)"""
+    x = _gpu(x, torch.complex64, "x")
+    H, W = x.shape[-2:]
+    g = torch.empty_like(x)
+    call("ipdm_tv_grad_c64", _ptr(x), _ptr(g), x.numel() // (H * W), H, W, _stream())
+    return g
+
+
 def nrmse(img, ref):
     """per-image ||img - ref|| / ||img|| (the reference's argument order); img (n, ...), ref same shape or one image"""
     img, ref = _gpu(img, torch.float32, "img"), _gpu(ref, torch.float32, "ref")

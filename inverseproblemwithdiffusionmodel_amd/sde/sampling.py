@@ -21,28 +21,45 @@ _PREDICTORS = {}
 
 
 class _Noise:
-    """N(0,1) draws shaped like x: Philox kernel keyed by (seed, call counter) on GPUs"""
+    """N(0,1) draws shaped like x: Philox kernel keyed by (seed, GLOBAL sample id, call counter) on GPUs"""
 
     def __init__(self, seed=0):
-        self.seed, self.count, self.fn = seed, 0, None
+        self.seed, self.count, self.fn, self.sample_offset = seed, 0, None, 0
 
     def __call__(self, x):
         if self.fn is not None:
             return self.fn(x).to(x.device)
         self.count += 1
-        return ops.philox_normal(tuple(x.shape), x.device, seed=self.seed, step_id=self.count)
+        return ops.philox_normal(tuple(x.shape), x.device, seed=self.seed, sample_offset=self.sample_offset, step_id=self.count)
 
 
 noise_like = _Noise()
+_SHARD = {"total": None, "lo": 0}      # set_shard(): this process holds samples [lo, lo + B) of a batch of `total`
 
 
-def set_noise_source(fn=None, seed=0):
-    """fn(like) -> tensor replaces the generator (None: Philox with `seed`)"""
-    noise_like.fn, noise_like.seed, noise_like.count = fn, seed, 0
+def set_noise_source(fn=None, seed=0, sample_offset=0):
+    """fn(like) -> tensor replaces the generator (None: Philox with `seed`; sample_offset: first global sample id of
+    this process' block, so that a sample's noise does not depend on how the batch is sharded)"""
+    noise_like.fn, noise_like.seed, noise_like.count, noise_like.sample_offset = fn, seed, 0, sample_offset
+
+
+def set_shard(total=None, lo=0):
+    """a batch sharded over the ranks of torch.distributed: LangevinCorrector's step size couples the batch through two
+    means over per-sample norms (sde/sampling.py:281-283 of the reference); with set_shard(total, lo) those means are taken
+    over ALL `total` samples -- every rank adds its per-sample norms into its rows of a zero vector, one all-reduce(SUM)
+    (exact: the other ranks add zeros), then the same .mean() a single process computes: bit-identical to the unsharded run."""
+    _SHARD["total"], _SHARD["lo"] = total, lo
 
 
 def _sample_norm_mean(v):
-    return ops.sample_norm(v).mean()
+    norms = ops.sample_norm(v)
+    total = _SHARD["total"]
+    if total is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        buf = torch.zeros(total, dtype=norms.dtype, device=norms.device)
+        buf[_SHARD["lo"]:_SHARD["lo"] + norms.shape[0]] = norms
+        torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM)
+        return buf.mean()
+    return norms.mean()
 
 
 def register_predictor(cls=None, *, name=None):
@@ -193,8 +210,8 @@ class LangevinCorrector(Corrector):
             raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
 
     def update_fn(self, x, t):
-        """NB the step size couples the batch through the two .mean()s (sde/sampling.py:281-283): a batch sharded
-        over GPUs is a set of independent runs unless those two scalars are all-reduced by the caller."""
+        """NB the step size couples the batch through the two .mean()s (sde/sampling.py:281-283); set_shard() makes them
+        means over the whole sharded batch (one small all-reduce each)."""
         alpha = _alpha(self.sde, t)
         x_mean = x
         for _ in range(self.n_steps):

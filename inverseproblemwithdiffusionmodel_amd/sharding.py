@@ -4,8 +4,43 @@ weights), so the data path has NO collective: global sample ids are block-partit
 sample's Langevin noise is keyed by its global id (results do not depend on the number of GPUs), and
 the only exchange is one all-reduce(SUM) of seven moment planes at the end (RCCL over xGMI on GPUs, gloo in
 the CPU tests)."""
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def init_distributed():
+    """-> (world, rank, device) from the launcher's environment (torchrun: WORLD_SIZE / RANK / LOCAL_RANK / MASTER_*), one
+    process per GPU, backend "nccl" (= RCCL over xGMI).  Rehearsal knobs for a one-GPU box: IPDM_DIST_BACKEND=gloo (RCCL
+    allows one rank per card) and IPDM_BENCH_DEVICE=<index> (every rank on that card).  World 1: no process group."""
+    world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    dev_index = int(os.environ.get("IPDM_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("IPDM_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return world, rank, device
+
+
+def gather_samples(local, total, world, rank):
+    """every rank's block of samples -> the (total, ...) tensor in global sample order on every rank: one all-reduce(SUM)
+    of a zero-filled buffer in which a rank fills only its own rows (adding zeros is exact, so the result carries the
+    ranks' bits unchanged whatever the backend's reduction order)"""
+    if world == 1:
+        return local
+    lo, hi = shard_range(total, world, rank)
+    real = torch.view_as_real(local) if local.is_complex() else local
+    buf = torch.zeros((total,) + tuple(real.shape[1:]), dtype=real.dtype, device=real.device)
+    buf[lo:hi] = real[: hi - lo]
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return torch.view_as_complex(buf) if local.is_complex() else buf
 
 
 def shard_sizes(total, world_size):
@@ -25,9 +60,12 @@ def moment_planes(samples):
     sum|x|, sum|x|^2, sum angle, sum angle^2, sum Re, sum Im, sum|angle|  (helpers/metrics.py:77-92 semantics: the
     reference's phase std is np.std(np.abs(angle)) -- its real-valued branch takes |.| before the std).
     GPU tensors: one kernel (ipdm_posterior_moments_c64); CPU tensors (the gloo tests): the same sums in torch."""
+    if samples.shape[0] == 0:                                  # a rank without samples contributes zeros
+        return torch.zeros((7,) + tuple(samples.shape[1:]), dtype=torch.float64, device=samples.device)
     if samples.is_cuda:
         from . import ops
         return ops.posterior_moment_planes(samples.to(torch.complex64).contiguous())
+    # host tensors only reach this line from the CPU (gloo) tests of the collective; the product path is the kernel above
     mag, ph = samples.abs().float().double(), samples.angle().float().double()
     return torch.stack([mag.sum(0), (mag * mag).sum(0), ph.sum(0), (ph * ph).sum(0),
                         samples.real.double().sum(0), samples.imag.double().sum(0), ph.abs().sum(0)])

@@ -1053,6 +1053,54 @@ def test_conv2d_winograd_bx3(ops, B, Cin, Cout, H, W, res, dil, fmt):
     assert torch.equal(raw, raw2)
 
 
+# ---- TV baseline -----------------------------------------------------------------------------------------------------
+def test_tv_value_and_gradient_vs_autograd(ops):
+    """ipdm_tv_c64 / ipdm_tv_grad_c64 against the published definition (oracle/tv.py) and torch autograd of it on the CPU
+    (complex parameter: the gradient torch.optim.Adam would see), including zero differences (flat patches -> 0)"""
+    from oracle import tv as otv
+    gen = torch.Generator().manual_seed(5)
+    x = torch.complex(torch.randn(3, 1, 20, 28, generator=gen), torch.randn(3, 1, 20, 28, generator=gen))
+    x[0, 0, 4:9, 5:11] = 0.7 - 0.2j                                   # flat patch: zero differences inside
+    xp = x.clone().requires_grad_(True)
+    val = otv.total_variation(xp)
+    val.sum().backward()
+    got_v = ops.tv_value(x.cuda()).cpu().reshape(3, 1)
+    np.testing.assert_allclose(got_v.numpy(), val.detach().double().numpy(), rtol=1e-6)
+    got_g = ops.tv_grad(x.cuda()).cpu()
+    np.testing.assert_allclose(torch.view_as_real(got_g).numpy(), torch.view_as_real(xp.grad).numpy(), atol=2e-6)
+
+
+def test_tv_map_model_vs_autograd_adam(ops):
+    """MAPModel.fit (HIP: closed-form data gradient + TV gradient kernel + Adam kernel) against the same 25 epochs of
+    torch autograd + torch.optim.Adam on the CPU oracle operators"""
+    from oracle import tv as otv
+    from inverseproblemwithdiffusionmodel_amd.ncsn.linear_transforms.undersampling_fourier import SENSE
+    from inverseproblemwithdiffusionmodel_amd.ncsn.models.MAP_optimizers import MAPModel, TotalVariation
+    from inverseproblemwithdiffusionmodel_amd.synthetic import phantom_image
+    H = W = 32
+    op = SENSE("exp", 4, 8, 0.05, (1, H, W), seed=0)
+    img = phantom_image(H, W, seed=1)
+    meas = op(img.cuda())
+    model = MAPModel(meas, op, TotalVariation(), 0.01)
+    x = model.fit(25, 1e-2).numpy()
+    maps = torch.from_numpy(op.sens_maps.numpy()).to(torch.complex64)          # (4, H, W)
+    mask = op.random_under_fourier.mask.reshape(-1, 1, 1, W)[0].to(torch.float32)
+
+    def fft2c(t):
+        return torch.fft.fftshift(torch.fft.fft2(torch.fft.ifftshift(t, dim=(-1, -2)), norm="ortho"), dim=(-1, -2))
+
+    def ifft2c(t):
+        return torch.fft.fftshift(torch.fft.ifft2(torch.fft.ifftshift(t, dim=(-1, -2)), norm="ortho"), dim=(-1, -2))
+
+    fwd = lambda X: mask * fft2c(maps[:, None, None] * X[None])
+    adj = lambda S: (torch.conj(maps[:, None, None]) * ifft2c(S)).sum(0)
+    m_cpu = meas.cpu()
+    assert torch.allclose(fwd(img), m_cpu, atol=1e-5)                          # the oracle operators are the op's
+    want = otv.tv_map(m_cpu, fwd, adj, 0.01, 1e-2, 25).numpy()
+    assert np.abs(x - want).max() < 2e-4 * np.abs(want).max()
+    assert np.abs(want - adj(m_cpu).numpy()).max() > 0.05 * np.abs(want).max()   # 25 epochs moved the image
+
+
 # ---- on-device reporting ---------------------------------------------------------------------------------------------
 def test_device_metrics_match_host_definitions(ops):
     """NRMSE / SSIM / posterior mean-std on the GPU against the numpy definitions of helpers/metrics.py (the reference's
