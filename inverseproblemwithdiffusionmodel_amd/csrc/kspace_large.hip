@@ -293,12 +293,17 @@ __global__ __launch_bounds__(256) void langevin_planes_kernel(float* x_re, float
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------
+// the dynamic-LDS limit is raised ONCE per kernel instantiation, to the largest strip any call can ask for (a static flag per
+// template instance: no host API call on the per-step launch path, none during hipGraph capture after the first use)
 template <typename K>
 static int set_lds(K kernel, size_t bytes) {
-  if (bytes <= 64 * 1024) return IPDM_OK;
+  static bool done = false;                      // one flag per K (per kernel instantiation)
+  if (done || bytes <= 64 * 1024) return IPDM_OK;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)bytes);
-  return e == hipSuccess ? IPDM_OK : (int)e;
+                                     (int)strip_lds_bytes(2048));        // 2048: the largest side large_ok() admits
+  if (e != hipSuccess) return (int)e;
+  done = true;
+  return IPDM_OK;
 }
 
 template <class F>

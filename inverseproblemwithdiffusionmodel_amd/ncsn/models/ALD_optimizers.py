@@ -241,7 +241,14 @@ class ALDInvSegProximalRealImag(ALDOptimizer):
             st["noise_re"] = torch.empty(B, 1, H, W, device=dev)
             st["noise_im"] = torch.empty(B, 1, H, W, device=dev)
         if self._seg_active():
+            if kwargs.get("label") is None:
+                raise ValueError("segmentation-likelihood guidance is active (seg_start_time < 1): pass label=(B or 1, 1, H, W) int64")
             label = kwargs["label"].to(dev, torch.int64)
+            n_cls = getattr(self.seg, "out_channels", None)
+            lo_, hi_ = int(label.min()), int(label.max())              # host check, outside the captured graph
+            if lo_ < 0 or (n_cls is not None and hi_ >= n_cls):
+                raise IndexError(f"label values {lo_}..{hi_} outside the segmentation network's {n_cls} classes "
+                                 "(torch.gather in the reference's compute_seg_grad raises here too)")
             if label.shape[0] != B:
                 label = label.expand(B, *label.shape[1:])
             st["seg_label"] = torch.cat([label, label], dim=0).contiguous()   # real planes | imaginary planes

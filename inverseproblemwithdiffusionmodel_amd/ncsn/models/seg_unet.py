@@ -126,9 +126,17 @@ class UNet(nn.Module):
         return down.backward_input(g_d, sd)
 
     @torch.no_grad()
+    def _check_size(self, x):
+        """every stride-2 level halves the image and the transposed convolutions double it back: H and W must be multiples
+        of 2^len(strides), otherwise the skip concatenations / the backward walk meet mismatched shapes mid-chain"""
+        m = 2 ** len(self.strides)
+        if x.dim() != 4 or x.shape[-2] % m or x.shape[-1] % m:
+            raise ValueError(f"UNet: input {tuple(x.shape)}: H and W must be multiples of {m} (2^len(strides))")
+
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("UNet: expected GPU tensors (no CPU fallback in this build)")
+        self._check_size(x)
         return self._fwd(self.model, x.contiguous().float())[0]
 
     @torch.no_grad()
@@ -138,6 +146,7 @@ class UNet(nn.Module):
         assert mode in ["full", "FG"]
         if not x.is_cuda:
             raise RuntimeError("UNet.loglh_grad: expected GPU tensors (no CPU fallback in this build)")
+        self._check_size(x)
         label = label.to(x.device, torch.int64)
         if label.shape[0] != x.shape[0]:
             label = label.expand(x.shape[0], *label.shape[1:])

@@ -134,6 +134,17 @@ def sense_workspace(B, n_coils, H, W, device):
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device) if nbytes else None
 
 
+def _check_work(work, B, n_coils, H, W, what):
+    """the SENSE kernels write `work` as n_coils * B complex images: a short / foreign buffer is an out-of-bounds GPU write"""
+    need = _lib.lib.ipdm_sense_workspace_bytes(B, n_coils, H, W)
+    if need == 0:
+        return
+    if (not isinstance(work, torch.Tensor) or not work.is_cuda or work.dtype != torch.float32 or not work.is_contiguous()
+            or work.numel() * 4 < need):
+        raise ValueError(f"{what}: `work` must be a contiguous float32 GPU tensor of >= {need} bytes "
+                         f"(ops.sense_workspace({B}, {n_coils}, {H}, {W}, device))")
+
+
 def _large_image(H, W):
     return H * W > 16384
 
@@ -169,6 +180,7 @@ def sense_l2prox(z_re, z_im, y, sens_f32, mask_u8, coef, out_re=None, out_im=Non
     out_re = torch.empty_like(z_re) if out_re is None else out_re
     out_im = torch.empty_like(z_im) if out_im is None else out_im
     work = sense_workspace(B, sens_f32.shape[0], H, W, z_re.device) if work is None else work
+    _check_work(work, B, sens_f32.shape[0], H, W, "sense_l2prox")
     call("ipdm_sense_l2prox_f32", _ptr(z_re), _ptr(z_im), _ptr(y), _ptr(sens_f32), _ptr(mask_u8), mask_u8.shape[0],
          float(coef), _ptr(out_re), _ptr(out_im), _ptr(work), B, sens_f32.shape[0], H, W, _stream())
     return out_re, out_im
@@ -187,6 +199,7 @@ def ald_sense_step(x_re, x_im, g_re, g_im, y, sens_f32, mask_u8, work, step=0.0,
     B = x_re.numel() // (H * W)
     if g_re.numel() != x_re.numel() or g_im.numel() != x_im.numel() or y.numel() != sens_f32.shape[0] * B * H * W:
         raise ValueError("ald_sense_step: operand sizes do not match the state")
+    _check_work(work, B, sens_f32.shape[0], H, W, "ald_sense_step")
     call("ipdm_ald_sense_step_f32", _ptr(x_re), _ptr(x_im), _ptr(g_re), _ptr(g_im), _ptr(noise_re), _ptr(noise_im),
          float(step), float(noise_scale), int(seed), int(sample_offset), int(step_id), _ptr(dev_sched),
          _ptr(y), _ptr(sens_f32), _ptr(mask_u8), mask_u8.shape[0], float(coef), _ptr(work), B, sens_f32.shape[0], H, W,
@@ -208,6 +221,8 @@ def singlecoil_prox(z_re, z_im, y, mask_u8, coef, mode, out_re=None, out_im=None
     out_im = torch.empty_like(z_im) if out_im is None else out_im
     if work is None and _large_image(H, W):
         work = sense_workspace(B, 1, H, W, z_re.device)
+    if work is not None or _large_image(H, W):
+        _check_work(work, B, 1, H, W, "singlecoil_prox")
     call("ipdm_singlecoil_prox_f32", _ptr(z_re), _ptr(z_im), _ptr(y), _ptr(mask_u8), mask_u8.shape[0], float(coef),
          int(mode), _ptr(out_re), _ptr(out_im), _ptr(work), B, H, W, _stream())
     return out_re, out_im
@@ -223,6 +238,8 @@ def ald_singlecoil_step(x_re, x_im, g_re, g_im, y, mask_u8, mode, step=0.0, nois
     B = x_re.numel() // (H * W)
     if work is None and _large_image(H, W):
         work = sense_workspace(B, 1, H, W, x_re.device)
+    if work is not None or _large_image(H, W):
+        _check_work(work, B, 1, H, W, "ald_singlecoil_step")
     call("ipdm_ald_singlecoil_step_f32", _ptr(x_re), _ptr(x_im), _ptr(g_re), _ptr(g_im), _ptr(noise_re), _ptr(noise_im),
          float(step), float(noise_scale), int(seed), int(sample_offset), int(step_id), _ptr(dev_sched), _ptr(y),
          _ptr(mask_u8), mask_u8.shape[0], float(coef), int(mode), _ptr(work), B, H, W, _stream())
@@ -410,6 +427,9 @@ def instnorm_plus_coef(x, alpha, gamma, beta):
     part = getattr(x, "_ipdm_partials", None)
     if part is not None:
         del x._ipdm_partials             # single use: whatever touches the tensor afterwards cannot meet stale statistics
+        part, tag = part
+        if tag != (x._version, x.data_ptr()):        # written in place since the convolution produced it: read the tensor
+            part = None
     if part is not None and USE_STATS_EPILOGUE and tuple(part.shape[:2]) == (B, C):
         call("ipdm_instnorm_plus_coef_partials_f32", _ptr(part), int(part.shape[2]), _ptr(alpha), _ptr(gamma), _ptr(beta),
              _ptr(coef), B, C, _stream())
@@ -946,7 +966,7 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
                 part = None
         call(f"ipdm_conv2d_wino_{U.fmt}_f32", *args, _stream())
     if part is not None:
-        out._ipdm_partials = part
+        out._ipdm_partials = (part, (out._version, out.data_ptr()))
     if CONV_TRACE is not None:
         e1.record()
         CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, fmt=U.fmt, res=residual is not None,

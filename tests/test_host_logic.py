@@ -289,3 +289,37 @@ def test_real_data_front_end(tmp_path):
     assert vol.shape == (6, 1, 32, 32) and vol.dtype == torch.complex64
     with pytest.raises(FileNotFoundError):
         ld.load_data("ACDC", "val")
+
+
+def test_sample_grid_report_and_plot(tmp_path):
+    """helpers/visualizations.py (reference :58-192): the numbers of the sample-grid figure -- per-sample SNR / NRMSE / SSIM,
+    std maps, Spearman tables against scipy and against a rank-based Pearson restatement -- and the figure file itself"""
+    import pickle
+    import torch
+    from scipy.stats import rankdata
+    from inverseproblemwithdiffusionmodel_amd.helpers import visualizations as vz, metrics as hm
+    rng = np.random.default_rng(7)
+    H = W = 24
+    orig = (rng.random((1, 1, H, W)) * np.exp(1j * 0.3 * rng.standard_normal((1, 1, H, W)))).astype(np.complex64)
+    rec = (orig + 0.05 * (rng.standard_normal((3, 1, H, W)) + 1j * rng.standard_normal((3, 1, H, W)))).astype(np.complex64)
+    d = str(tmp_path)
+    torch.save(torch.from_numpy(orig), os.path.join(d, "original.pt"))
+    torch.save(torch.from_numpy(rec), os.path.join(d, "reconstructions.pt"))
+    with open(os.path.join(d, "args_dict.pkl"), "wb") as f:
+        pickle.dump({"lr_scaled": 1.0, "step_lr": 9e-7}, f)
+    rep = vz.sample_grid_report(d)
+    want = hm.compute_metrics(["NRMSE", "SSIM"], np.abs(rec), np.abs(orig))
+    for k in ("NRMSE", "SSIM"):
+        np.testing.assert_allclose(rep["metrics"][k], want[k], rtol=1e-5)
+    np.testing.assert_allclose(rep["metrics"]["SNR"], hm.compute_snr(rec))
+    np.testing.assert_allclose(rep["mag_std"], np.abs(rec).std(axis=0))
+    assert rep["spearman"].shape == (3, 2, 2)
+    a = np.abs(rec[1, 0] - orig[0, 0]).ravel()
+    b = np.abs(rec).std(axis=0).ravel()
+    ra, rb = rankdata(a), rankdata(b)                                # Spearman = Pearson of the ranks
+    assert abs(rep["spearman"][1, 0, 0] - np.corrcoef(ra, rb)[0, 1]) < 1e-12
+    fig = vz.create_sample_grid_plot(d, if_save=True)
+    assert fig is not None and os.path.getsize(os.path.join(d, "samples.png")) > 10000
+    curves, _ = vz.metric_vs_hyperparam([d], ["NRMSE"], ["lr_scaled"], {"lr_scaled": 1.0}, no_plot=True)
+    assert curves[("lr_scaled", "NRMSE")][0].tolist() == [1.0]
+
