@@ -36,8 +36,9 @@ constexpr int X_V_ELEMS = 16 * X_KC * X_TILES;                   // 16384 floats
 // LDS-DMA (buffer_load ... lds: no VGPRs, hardware zero padding) and the 4x4 patches are read from there
 constexpr int X_RR = 2 * X_TY + 2, X_RC = 2 * X_TX + 2;          // 10 x 34
 constexpr int X_RCH = 384;                                       // floats per channel (6 wave-instructions of 64 lanes)
-constexpr int X_R_ELEMS = 27 * 256;                              // >= 16 x 384 (dword form) and 27 quad pieces (DMA4, 8x8 tiles)
-constexpr size_t X_LDS_BYTES = (2 * (size_t)X_V_ELEMS + X_R_ELEMS) * sizeof(float);   // 128 KiB + 24 KiB
+constexpr int X_R_ELEMS = 32 * 256;                              // >= 16 x 384 (dword form), 27 quad pieces (DMA4, 8x8 tiles) and
+                                                                 // eight wave-private 4 KiB blocks (f16x2 + DMA4)
+constexpr size_t X_LDS_BYTES = (2 * (size_t)X_V_ELEMS + X_R_ELEMS) * sizeof(float);   // 128 KiB + 32 KiB = all of a CU's LDS
 
 // U[p = a*4+b][co][ci] = sum_ij G[a][i] g[co][ci][i][j] G[b][j], split into three bf16 pieces, stored as MFMA
 // A fragments: [p][cc = ci/16][ct = co/32][piece][h][r][8]  (lane (r, h) holds ci = 16cc + 8h .. +7 of co = 32ct + r)
@@ -608,6 +609,14 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   constexpr int QN = POLY ? PPH * QC : (2 * TY + 2) * QC;     // quads per channel
   constexpr int NI = (X_KC * QN + 63) / 64;                   // wave-instructions per chunk
   static_assert(NI >= 24 && NI <= 32 && NI * 256 <= X_R_ELEMS, "quad image fits the raw stage; pieces 0..23 exist");
+  // f16x2 + 16-byte DMA: the raw stage is WAVE-PRIVATE -- wave w fetches exactly the two channels (2w, 2w+1) whose patches its
+  // own threads transform, into its own 4 KiB block (2 * QN quads <= 256 = four wave-instructions).  No other wave ever reads
+  // that block, so the raw data needs no barrier at all: a wave waits for ITS DMA with a counted vmcnt, reads its patches into
+  // registers and re-issues the DMA of the chunk after -- a whole chunk ahead of its use; the one barrier left per chunk is
+  // the V stage's.  (Shared raw stage: barrier -> DMA -> landing -> barrier -> patch reads -> barrier was the critical path,
+  // 4.1 k cycles per chunk against 1.5 k of matrix work.)
+  constexpr bool WPRIV = HX && DMA4;
+  static_assert(!WPRIV || 2 * QN <= 256, "a wave's two channels fit four DMA instructions");
   static_assert(TX * TY == X_TILES, "64 tiles per workgroup");
   constexpr int RC = 2 * TX + 2, RR = 2 * TY + 2;            // raw region: 34 x 10 or 18 x 18 pixels (<= X_RCH)
   static_assert(RC * RR <= X_RCH, "raw region fits its LDS slot");
@@ -674,11 +683,12 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     if constexpr (DMA4) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int e = dma_piece(k) * 64 + lane;
-        const int cin = e / QN, qq = e - cin * QN;
+        const int e = (WPRIV ? k : dma_piece(k)) * 64 + lane;
+        const int cl = e / QN, qq = e - cl * QN;                // WPRIV: cl = channel of the wave's pair (>= 2: padding lanes,
+        const int cin = WPRIV ? 2 * wave + cl : cl;             //        which write zeros into the tail of the wave's own block)
         const int rr = qq / QC, qc = qq - rr * QC;
         const int gy = POLY ? (rr < 16 ? rr : -1) : g.y0 - 1 + rr, gx0 = g.x0 - 4 + 4 * qc;
-        const bool ok = e < X_KC * QN && gy >= 0 && gy < a.H && gx0 >= 0 && gx0 < a.W;
+        const bool ok = e < (WPRIV ? 2 : X_KC) * QN && gy >= 0 && gy < a.H && gx0 >= 0 && gx0 < a.W;
         dma_off[k] = ok ? (cin * HW + gy * a.W + gx0) * 4 : 0x40000000;
       }
     } else {
@@ -699,8 +709,9 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the 16-byte form only exists for gfx950: keep it out of the host pass
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(rs + dma_piece(k) * 256),
-                                                 16, dma_off[k], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            x_rsrc, (__attribute__((address_space(3))) void*)(rs + (WPRIV ? wave * 4 + k : dma_piece(k)) * 256), 16, dma_off[k],
+            soff, 0, 0);
 #endif
       }
     } else {
@@ -741,7 +752,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   const int r_lane = DMA4 ? (2 * (mytile / TX)) * RC4 + 2 * (mytile % TX) + 2 : (2 * (mytile / TX)) * RC + 2 * (mytile % TX);
   auto read_patch_to = [&](float (&dreg)[16], int kc) {
     if constexpr (POLY) {
-      const float* rp = rs + kc * (QN * 4);
+      const float* rp = WPRIV ? rs + wave * 1024 + (kc & 1) * (QN * 4) : rs + kc * (QN * 4);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
@@ -751,7 +762,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       // column 2txl+3 is the left neighbour tile's second element and 2txl+6 the right neighbour's first (lanes of a
       // 16-lane DPP row are consecutive tiles of a tile row), the two tiles at the ends of a tile row read theirs:
       // 8 instead of 12 LDS instructions and half the LDS bytes per patch.
-      const float* rp = rs + kc * (QN * 4) + r_lane;          // -> column 2txl+2
+      const float* rp = (WPRIV ? rs + wave * 1024 + (kc & 1) * (QN * 4) : rs + kc * (QN * 4)) + r_lane;   // -> column 2txl+2
       const int txl = mytile % TX;
       const bool first = txl == 0, last = txl == TX - 1;
       const int edge = first ? 1 : 4;                         // column 2txl+3 (first) / 2txl+6 (last); others: unused
@@ -881,6 +892,14 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   uint4 afr[2][2][NPC];
   load_A(afr[0], p0, cur_g.c0, cur_g.co_tile);
   set_dma_geo(cur_g);
+  // workgroup barrier for LDS data only: __syncthreads() also drains vmcnt, i.e. would wait for a DMA just issued
+  auto lds_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0): this wave's LDS stores / reads are done
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
   issue_dma(0);
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
@@ -916,7 +935,55 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       const bool a_next = ch + 1 >= n_chunks;
       const int a_chunk = a_next ? next_g.c0 : cur_g.c0 + ch + 1;
       const int a_cot = a_next ? next_g.co_tile : cur_g.co_tile;
-      if constexpr (HX) {
+      if constexpr (WPRIV) {
+        // this wave's DMA of chunk c+1 (issued a chunk ago) and the fragments of position p0 have landed: fragments of position
+        // p0+1 first (older than the next DMA in the in-order vmcnt queue), the wave's own patches into registers, and at once
+        // the DMA of chunk c+2 into the block just read -- no barrier: nobody else reads it.  Transform / split / packed stores
+        // are dealt over the four MFMA steps; the chunk ends with the V-stage barrier (LDS only: no vmcnt drain).
+        uint4 bsh[2][2];
+        float va[16], vb[16];
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+        load_A(afr[1], p0 + 1, cur_g.c0 + ch, cur_g.co_tile);
+        read_patch_to(va, 2 * wave);
+        read_patch_to(vb, 2 * wave + 1);
+        load_Bh(bsh[0], cur, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the patches are in registers
+        IPDM_TR(5);
+        issue_dma(dma_chunk);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<4>([&](auto sc) {
+          constexpr int st = decltype(sc)::value;
+          constexpr int pi = st >> 1, tg = st & 1;
+          if constexpr (st < 3) load_Bh(bsh[(st + 1) & 1], cur, (st + 1) >> 1, (st + 1) & 1);
+          if constexpr (st == 0) transform(va);
+          if constexpr (st == 1) transform(vb);
+          if constexpr (st == 2) {
+            store_pair(nxt, va, vb, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+            load_A(afr[0], p0, a_chunk, a_cot);
+          }
+          if constexpr (st == 3) store_pair(nxt, va, vb, std::integral_constant<int, 8>{}, std::integral_constant<int, 16>{});
+          const f16x8 bh = __builtin_bit_cast(f16x8, bsh[st & 1][0]), bl = __builtin_bit_cast(f16x8, bsh[st & 1][1]);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            f32x16 v = acc[pi][c][tg];
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][1]), bh, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][0]), bl, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][0]), bh, v, 0, 0, 0);
+            acc[pi][c][tg] = v;
+          }
+          if constexpr (st < 3) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // next step's operand reads first
+          if constexpr (st == 2) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);    // ... and the fragment requests
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
+            if constexpr (st >= 2) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          IPDM_TR(1 + st);
+        });
+      } else if constexpr (HX) {
         // f16x2 chunk.  With three MFMAs per product the matrix work of a chunk (48 MFMAs per wave) no longer covers a DMA
         // round trip issued a quarter chunk in: the raw patches are read into registers FIRST, the barrier that frees the raw
         // stage follows at once and the DMA of chunk c+2 is issued right behind it (a whole chunk to land); the transform,
@@ -1044,9 +1111,13 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
         }
       });
       }
-      __builtin_amdgcn_s_waitcnt(0);                          // the DMA has landed
-      IPDM_TR(6);
-      __syncthreads();
+      if constexpr (WPRIV) {
+        lds_barrier();
+      } else {
+        __builtin_amdgcn_s_waitcnt(0);                        // the DMA has landed
+        IPDM_TR(6);
+        __syncthreads();
+      }
       IPDM_TR(7);
     }
     if (a.dbg) t2 = __builtin_amdgcn_s_memtime();

@@ -653,11 +653,17 @@ def test_wino_bx3_statistics_epilogue(ops, B, Cin, Cout, H, W, pool, res, fmt):
     assert P == 2 * ((W + 31) // 32) * ((H + 7) // 8)
     y0 = ops.conv2d_wino_bx3(x, U, b, r, pool2=pool)
     y1, y1a = ops.conv2d_wino_bx3(x, U, b, r, pool2=pool, act_out=ops.ACT_ELU, want_stats=True)
-    assert torch.equal(y0, y1) and hasattr(y1, "_ipdm_partials") and tuple(y1._ipdm_partials.shape) == (B, Cout, P, 3)
-    assert float(y1._ipdm_partials[..., 0].sum(dim=2).min()) == oh * ow == float(y1._ipdm_partials[..., 0].sum(dim=2).max())
+    assert torch.equal(y0, y1) and hasattr(y1, "_ipdm_partials")
+    part, tag = y1._ipdm_partials                                        # (partials, (version, data_ptr) of the tensor)
+    assert tuple(part.shape) == (B, Cout, P, 3) and tag == (y1._version, y1.data_ptr())
+    assert float(part[..., 0].sum(dim=2).min()) == oh * ow == float(part[..., 0].sum(dim=2).max())
     alpha, gamma, beta = (torch.randn(Cout, generator=gen).cuda() for _ in range(3))
     c_part = ops.instnorm_plus_coef(y1, alpha, gamma, beta)
     assert not hasattr(y1, "_ipdm_partials")                                # single use
+    y2 = ops.conv2d_wino_bx3(x, U, b, r, pool2=pool, want_stats=True)
+    y2.mul_(2.0)                                                            # written in place: the partials are stale
+    c_stale = ops.instnorm_plus_coef(y2, alpha, gamma, beta)                # ... and must be ignored
+    assert (c_stale[..., 0] - 2.0 * c_part[..., 0]).abs().max() <= 1e-4 * c_part[..., 0].abs().max() + 1e-5
     c_full = ops.instnorm_plus_coef(y0, alpha, gamma, beta)                 # no partials on y0: reads the tensor
     assert (c_part - c_full).abs().max() <= 2e-5 * c_full.abs().max()
     yd = y0.double()
