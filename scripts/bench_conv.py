@@ -13,7 +13,8 @@ B = int(os.environ.get("BENCH_B", 28))
 ONLY = os.environ.get("BENCH_ONLY")          # e.g. "0,1,2": indices into SHAPES
 NO_MIOPEN = os.environ.get("BENCH_NO_MIOPEN") == "1"
 WINO = os.environ.get("BENCH_WINO") == "1"     # Winograd F(2x2,3x3) path where eligible
-BX3 = os.environ.get("BENCH_BX3") == "1"       # bf16x3 split kernel (fp32-faithful on the bf16 matrix cores)
+BX3 = os.environ.get("BENCH_BX3") == "1"       # split-operand kernels (fp32-faithful on the 16-bit matrix cores)
+FMT = os.environ.get("BENCH_FMT", "hx2")       # ... which family: hx2 (two fp16 pieces) or bx3 (three bf16 pieces)
 FUSED = os.environ.get("BENCH_FUSED") == "1"   # ELU + InstanceNorm++ coefficients on the input, residual on the output
 SHAPES = [  # (count per forward, Cin, Cout, H, dil)
     (18, 128, 128, 128, 1), (9, 128, 128, 64, 1), (8, 256, 256, 64, 1), (17, 256, 256, 32, 1),
@@ -45,7 +46,7 @@ for idx, (cnt, ci, co, hw, dil) in enumerate(SHAPES):
     flop = 2.0 * B * hw * hw * ci * co * 9
     t_m = 1e9 if NO_MIOPEN else timeit(lambda: F.conv2d(x, w, bias, padding=dil, dilation=dil))
     if BX3 and WINO and ops.conv_wino_bx3_supported(ci, co, hw, hw, dil):
-        Uq = ops.conv_wino_bx3_weight(w)
+        Uq = ops.conv_wino_bx3_weight(w, fmt=FMT)
         t_o = timeit(lambda: ops.conv2d_wino_bx3(x, Uq, bias, dilation=dil))
         out = ops.conv2d_wino_bx3(x, Uq, bias, dilation=dil)
         ref64 = F.conv2d(x[:2].double(), w.double(), bias.double(), padding=dil, dilation=dil)
@@ -53,7 +54,7 @@ for idx, (cnt, ci, co, hw, dil) in enumerate(SHAPES):
         e_f = ((ops.conv2d_wino(x[:2].contiguous(), ops.conv_wino_weight(w), bias, dilation=dil).double() - ref64).abs().max() / ref64.abs().max()).item() if ops.conv_wino_supported(ci, co, hw, hw, dil) else float("nan")
         print(f"      rel-to-max error vs float64: wino-bx3 {e_w:.2e}   wino-fp32 {e_f:.2e}")
     elif BX3:
-        wq = ops.conv_bx3_weight(w)
+        wq = ops.conv_bx3_weight(w, fmt=FMT)
         t_o = timeit(lambda: ops.conv_bx3(x, wq, bias, dilation=dil, out=out))
         x64, w64 = x[:2].double(), w.double()
         ref64 = F.conv2d(x64, w64, bias.double(), padding=dil, dilation=dil)

@@ -4,7 +4,7 @@ set -e
 TAG=${1:-wino}; IDX=${2:-0}
 ROOT=$(cd "$(dirname "$0")/.." && pwd); cd "$ROOT"; export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/pmc_conv_$TAG; rm -rf "$OUT"; mkdir -p "$OUT"
-export BENCH_ONLY=$IDX BENCH_NO_MIOPEN=1
+export BENCH_ONLY=$IDX BENCH_NO_MIOPEN=1 BENCH_BX3=1 BENCH_WINO=1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT" -o p1 -- python3 scripts/bench_conv.py > "$OUT/log1.txt" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d "$OUT" -o p2 -- python3 scripts/bench_conv.py > "$OUT/log2.txt" 2>&1 || true
 python3 - "$OUT" <<'PY'

@@ -28,7 +28,14 @@ with open(f"profiles/{tag}_conv_pmc.csv", "w") as fh:
         fh.write('"%s",%d,%.1f,%.1f\n' % r)
 # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads -> x2
 per_launch = (2 * tot_f + tot_w) * 1024 / max(tot_n, 1)
+import subprocess, datetime
+try:
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except Exception:
+    commit = None
 json.dump({"hbm_bytes_per_launch": per_launch, "launches_profiled": tot_n,
+           "conv_impl": os.environ.get("IPDM_CONV_IMPL", "hx2"), "measured_at_commit": commit,
+           "measured_on": datetime.date.today().isoformat(), "tag": tag,
            "fetch_KiB_raw_total": tot_f, "write_KiB_raw_total": tot_w,
            "note": "mean over all convolution-kernel launches (conv_bx3_kernel, conv_wino_bx3_kernel; conv_mfma_kernel / conv_wino_kernel with IPDM_CONV_IMPL=f32) of bench.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                    "(gfx950 FETCH_SIZE halving corrected per MI355X_MICROARCH.md)"},
