@@ -238,6 +238,14 @@ int ipdm_trilinear_f32(const float* x, float* out, int planes, int in_d, int in_
 /* GroupNorm as per-(b,c) coefficients (mu, weight*rstd, bias) for ipdm_affine_act_f32 / the conv prologue */
 int ipdm_groupnorm_coef_f32(const float* x, const float* weight, const float* bias, float* coef,
                             int B, int C, int HW, int G, float eps, void* stream);
+/* GroupNorm (+ activation) of torch.cat([x1, x2], dim=1) WITHOUT the concatenation (the up path of NCSN++ feeds every block
+ * `torch.cat([h, hs.pop()], dim=1)`, models/ncsnpp.py:351): coefficients [B][C1+C2][3] from the two tensors' planes, then one
+ * pass that writes the normalised, activated, concatenated tensor.  IPDM_EUNSUPPORTED outside the single-read plane kernels
+ * (HW % 4 != 0, HW > 65536, more than 65535 planes): concatenate and use the one-tensor calls. */
+int ipdm_groupnorm_coef_cat_f32(const float* x1, int C1, const float* x2, int C2, const float* weight, const float* bias,
+                                float* coef, int B, int HW, int G, float eps, void* stream);
+int ipdm_affine_act_cat_f32(const float* x1, int C1, const float* x2, int C2, const float* coef, float* y, int B, int HW,
+                            int act, void* stream);
 /* y[b][o] = bias[o] + sum_i act(x[b][i]) * W[o][i]   (torch.nn.Linear weight layout [Out][In]) */
 int ipdm_linear_f32(const float* x, const float* W, const float* bias, float* y, int B, int In, int Out,
                     int act, void* stream);
@@ -299,6 +307,20 @@ int ipdm_maxpool3d5_f32(const float* x, float* y, int planes, int D, int H, int 
  * A 1x1 ipdm_conv2d_f32 over the 4*C gathered channels then IS the temporal convolution. */
 int ipdm_temporal_taps_f32(const float* x, float* out, int planes, int S, int T_in, int T_out, int mode, void* stream);
 
+/* Optional extras of the split-operand convolution calls below (`ext` may be NULL = all defaults).  A HOST struct, read when
+ * the call is made (its device pointer member is dereferenced by the kernel):
+ *   in_amax       f16x2 calls only: per-image max |x| [B] (ipdm_absmax_f32) -> dynamic range, see the f16x2 note; NULL = static
+ *   bias_bstride  bias index = image * bias_bstride + channel: Cout gives one bias ROW PER IMAGE (the reference's
+ *                 `h += Dense_0(act(temb))[:, :, None, None]` after a convolution, models/layerspp.py:252-254, folded into the
+ *                 epilogue); 0 = the usual per-channel bias
+ *   out_scale     result = (conv + bias + residual) * out_scale -- the skip_rescale of the score_sde blocks,
+ *                 (x + h) / sqrt(2) (models/layerspp.py:271-274), folded into the epilogue; 0 is read as 1 */
+typedef struct {
+  const float* in_amax;
+  int bias_bstride;
+  float out_scale;
+} ipdm_conv_ext_t;
+
 /* ---- fp32 convolution on the bf16 matrix cores ("bf16x3": exact three-way operand split, six
  * v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulation; fp32-faithful results at 2.67x the fp32 MFMA rate) ----
  * Same call sites, arguments and fused input / output options as ipdm_conv2d_f32 / ipdm_conv3d_f32; only the
@@ -309,10 +331,10 @@ int ipdm_conv_bx3_pack_weight(const float* w /* [Cout][Cin][k][k] or [Cout][Cin]
                               int Cin, int k, void* stream);
 int ipdm_conv2d_bx3_f32(const float* x, const void* packed, const float* bias, const float* coef, int act,
                         const float* residual, float* out, float* out_act, int act_out,
-                        int B, int Cin, int Cout, int H, int W, int k, int dilation, void* stream);
+                        int B, int Cin, int Cout, int H, int W, int k, int dilation, const ipdm_conv_ext_t* ext, void* stream);
 int ipdm_conv3d_bx3_f32(const float* x, const void* packed, const float* bias, const float* coef, int act,
                         const float* residual, float* out, float* out_act, int act_out,
-                        int B, int Cin, int Cout, int D, int H, int W, int k, int dilation, void* stream);
+                        int B, int Cin, int Cout, int D, int H, int W, int k, int dilation, const ipdm_conv_ext_t* ext, void* stream);
 
 /* Split-K form of the two calls above for shapes whose tiles alone leave most of the chip idle (small images at
  * small batch): ipdm_conv_bx3_splitk returns how many K parts pay (1 = use the plain call); with ksplit > 1 the parts
@@ -322,7 +344,7 @@ int ipdm_conv_bx3_splitk(int B, int D, int Cin, int Cout, int H, int W, int k, i
 int ipdm_conv_bx3_splitk_f32(const float* x, const void* packed, const float* bias, const float* coef, int act,
                              const float* residual, float* out, float* out_act, int act_out,
                              int B, int Cin, int Cout, int D, int H, int W, int k, int dilation, int volume, int ksplit,
-                             float* work, void* stream);
+                             float* work, const ipdm_conv_ext_t* ext, void* stream);
 
 /* One torch.optim.Adam step (no weight decay / amsgrad) in place on x along the ASCENT direction g, i.e. with
  * param.grad = -g as the reference's MAP optimizers hand it over (ncsn/models/MAP_optimizers.py:72-74,103-105);
@@ -341,7 +363,7 @@ int ipdm_conv2d_wino_bx3_supported(int Cin, int Cout, int H, int W, int dilation
  * pooled epilogue is not built (the caller then runs the convolution and ipdm_meanpool2_f32 separately) */
 int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
                              float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
-                             int pool2, void* stream);
+                             int pool2, const ipdm_conv_ext_t* ext, void* stream);
 /* The same launch with the statistics epilogue: besides the result it writes, per (image, output channel), P partials
  * (count, mean, sum of squared deviations about that mean) of the stored result -- one per (tile block, tile group), a
  * function of the image geometry only -- to stats [B][Cout][P][3]; ipdm_instnorm_plus_coef_partials_f32 turns them into the
@@ -355,43 +377,48 @@ int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const float* bias, c
 int ipdm_conv2d_wino_bx3_splitk(int Cin, int Cout, int H, int W, int dilation);
 int ipdm_conv2d_wino_bx3_splitk_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
                                     float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
-                                    int ksplit, float* work, void* stream);
+                                    int ksplit, float* work, const ipdm_conv_ext_t* ext, void* stream);
 int ipdm_conv2d_wino_bx3_stats_partials(int Cin, int Cout, int H, int W, int dilation, int pool2);
 int ipdm_conv2d_wino_bx3_stats_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
                                    float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
-                                   int pool2, float* stats, void* stream);
+                                   int pool2, float* stats, const ipdm_conv_ext_t* ext, void* stream);
 /* ---- "f16x2": the split-operand kernels above with TWO fp16 pieces per fp32 operand and THREE v_mfma_f32_32x32x16_f16 per
  * product (fp32 accumulation) -- half the matrix-core work and two thirds of the weight bytes of the three-way bf16 split.
  * fp32-faithful (error against float64 at or below the bf16 split's and the exact-fp32 kernel's on the networks' layer
  * shapes) under a RANGE contract: weights are scaled per output channel by a power of two at pack time (the inverse scale
  * rides in the blob); activations must satisfy |x| < 65504 (the Winograd calls pre-scale their input transform to keep that bound) -- beyond that the result
- * is NaN / inf (never a wrong finite number); the bx3 calls keep the whole fp32 exponent range.  Same arguments, semantics
+ * is NaN / inf (never a wrong finite number); the bx3 calls keep the whole fp32 exponent range.  DYNAMIC RANGE: `ext->in_amax`
+ * (NULL = the static contract above) is the per-image max |x| [B] of the input as ipdm_absmax_f32 writes it; the kernels
+ * then scale every image by the power of two that puts its maximum in [2^14, 2^15) and undo it in the epilogue (both exact), so
+ * ANY fp32 input is in range and values down to 2^-17 of an image's maximum keep all 22 bits.  (Ignored -- pass NULL -- when the
+ * call fuses an input normalisation / activation: the normalised values are what is split.)  Same other arguments, semantics
  * and replaced reference interface (torch.nn.Conv2d / Conv3d inside ncsn/models/layers.py:28-60) as their bx3 twins; the
  * shape rules (ipdm_conv_bx3_splitk, ipdm_conv2d_wino_bx3_supported / _splitk / _stats_partials) are shared. */
+int ipdm_absmax_f32(const float* x, float* amax /* [n_images] */, int n_images, int64_t per_image, void* stream);
 int64_t ipdm_conv_hx2_weight_bytes(int Cout, int Cin, int k);
 int ipdm_conv_hx2_pack_weight(const float* w /* [Cout][Cin][k][k] or [Cout][Cin][3][3][3] */, void* packed, int Cout,
                               int Cin, int k, void* stream);
 int ipdm_conv2d_hx2_f32(const float* x, const void* packed, const float* bias, const float* coef, int act,
                         const float* residual, float* out, float* out_act, int act_out,
-                        int B, int Cin, int Cout, int H, int W, int k, int dilation, void* stream);
+                        int B, int Cin, int Cout, int H, int W, int k, int dilation, const ipdm_conv_ext_t* ext, void* stream);
 int ipdm_conv3d_hx2_f32(const float* x, const void* packed, const float* bias, const float* coef, int act,
                         const float* residual, float* out, float* out_act, int act_out,
-                        int B, int Cin, int Cout, int D, int H, int W, int k, int dilation, void* stream);
+                        int B, int Cin, int Cout, int D, int H, int W, int k, int dilation, const ipdm_conv_ext_t* ext, void* stream);
 int ipdm_conv_hx2_splitk_f32(const float* x, const void* packed, const float* bias, const float* coef, int act,
                              const float* residual, float* out, float* out_act, int act_out,
                              int B, int Cin, int Cout, int D, int H, int W, int k, int dilation, int volume, int ksplit,
-                             float* work, void* stream);
+                             float* work, const ipdm_conv_ext_t* ext, void* stream);
 int64_t ipdm_conv_wino_hx2_weight_bytes(int Cout, int Cin);
 int ipdm_conv_wino_hx2_pack_weight(const float* w /* [Cout][Cin][3][3] */, void* U, int Cout, int Cin, void* stream);
 int ipdm_conv2d_wino_hx2_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
                              float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
-                             int pool2, void* stream);
+                             int pool2, const ipdm_conv_ext_t* ext, void* stream);
 int ipdm_conv2d_wino_hx2_splitk_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
                                     float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
-                                    int ksplit, float* work, void* stream);
+                                    int ksplit, float* work, const ipdm_conv_ext_t* ext, void* stream);
 int ipdm_conv2d_wino_hx2_stats_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
                                    float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
-                                   int pool2, float* stats, void* stream);
+                                   int pool2, float* stats, const ipdm_conv_ext_t* ext, void* stream);
 int ipdm_instnorm_plus_coef_partials_f32(const float* partials, int P, const float* alpha, const float* gamma,
                                          const float* beta /* may be NULL */, float* coef /* [B][C][3] */, int B, int C,
                                          void* stream);

@@ -13,6 +13,12 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: libipdm.so then bi
 #                              leaves torch and the kernels on two different runtimes ("no device", error 100).
 from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
+
+class ConvExt(ctypes.Structure):
+    """ipdm_conv_ext_t (include/ipdm.h): optional extras of the split-operand convolution calls"""
+    _fields_ = [("in_amax", c_void_p), ("bias_bstride", c_int), ("out_scale", c_float)]
+
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IPDM_LIB") or os.path.join(_HERE, "libipdm.so")     # IPDM_LIB: a diagnostic build (scripts/build_variant.sh)
 
@@ -56,6 +62,8 @@ SIGNATURES = {
     "ipdm_conv3x3_thin_f32": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "ipdm_trilinear_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "ipdm_groupnorm_coef_f32": [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
+    "ipdm_groupnorm_coef_cat_f32": [P, c_int, P, c_int, P, P, P, c_int, c_int, c_int, c_float, P],
+    "ipdm_affine_act_cat_f32": [P, c_int, P, c_int, P, P, c_int, c_int, c_int, P],
     "ipdm_linear_f32": [P, P, P, P, c_int, c_int, c_int, c_int, P],
     "ipdm_attention_f32": [P, P, P, P, c_int, c_int, c_int, c_float, P],
     "ipdm_axpby_f32": [P, P, P, c_int64, c_float, c_float, P],
@@ -72,29 +80,30 @@ SIGNATURES = {
     "ipdm_temporal_taps_f32": [P, P, c_int, c_int, c_int, c_int, c_int, P],
     "ipdm_conv_bx3_weight_bytes": [c_int, c_int, c_int],
     "ipdm_conv_bx3_pack_weight": [P, P, c_int, c_int, c_int, P],
-    "ipdm_conv2d_bx3_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 7 + [P],
-    "ipdm_conv3d_bx3_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 8 + [P],
+    "ipdm_conv2d_bx3_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 7 + [P, P],
+    "ipdm_conv3d_bx3_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 8 + [P, P],
     "ipdm_conv_bx3_splitk": [c_int] * 8,
-    "ipdm_conv_bx3_splitk_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 10 + [P, P],
+    "ipdm_conv_bx3_splitk_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 10 + [P, P, P],
     "ipdm_adam_ascent_f32": [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_int, P],
     "ipdm_conv_wino_bx3_weight_bytes": [c_int, c_int],
     "ipdm_conv_wino_bx3_pack_weight": [P, P, c_int, c_int, P],
     "ipdm_conv2d_wino_bx3_supported": [c_int, c_int, c_int, c_int, c_int],
-    "ipdm_conv2d_wino_bx3_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "ipdm_conv2d_wino_bx3_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "ipdm_conv2d_wino_bx3_stats_partials": [c_int, c_int, c_int, c_int, c_int, c_int],
     "ipdm_conv2d_wino_bx3_splitk": [c_int, c_int, c_int, c_int, c_int],
-    "ipdm_conv2d_wino_bx3_splitk_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
-    "ipdm_conv2d_wino_bx3_stats_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
+    "ipdm_conv2d_wino_bx3_splitk_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P],
+    "ipdm_conv2d_wino_bx3_stats_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P],
     "ipdm_conv_hx2_weight_bytes": [c_int, c_int, c_int],
     "ipdm_conv_hx2_pack_weight": [P, P, c_int, c_int, c_int, P],
-    "ipdm_conv2d_hx2_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 7 + [P],
-    "ipdm_conv3d_hx2_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 8 + [P],
-    "ipdm_conv_hx2_splitk_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 10 + [P, P],
+    "ipdm_absmax_f32": [P, P, c_int, c_int64, P],
+    "ipdm_conv2d_hx2_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 7 + [P, P],
+    "ipdm_conv3d_hx2_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 8 + [P, P],
+    "ipdm_conv_hx2_splitk_f32": [P, P, P, P, c_int, P, P, P, c_int] + [c_int] * 10 + [P, P, P],
     "ipdm_conv_wino_hx2_weight_bytes": [c_int, c_int],
     "ipdm_conv_wino_hx2_pack_weight": [P, P, c_int, c_int, P],
-    "ipdm_conv2d_wino_hx2_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
-    "ipdm_conv2d_wino_hx2_splitk_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
-    "ipdm_conv2d_wino_hx2_stats_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
+    "ipdm_conv2d_wino_hx2_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
+    "ipdm_conv2d_wino_hx2_splitk_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P],
+    "ipdm_conv2d_wino_hx2_stats_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P],
     "ipdm_instnorm_plus_coef_partials_f32": [P, c_int, P, P, P, P, c_int, c_int, P],
     "ipdm_zero_insert2_f32": [P, P, c_int, c_int, c_int, P],
     "ipdm_subsample2_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],

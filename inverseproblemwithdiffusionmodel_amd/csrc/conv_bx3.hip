@@ -132,6 +132,12 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
     it_gofs[i] = it_valid[i] ? gy * a.W + gx : 0;
   }
 
+  // f16x2, dynamic range: this image's power-of-two input scale and its inverse (a.in_amax: per-image max |x|)
+  [[maybe_unused]] float hx_in = 1.f, hx_out = 1.f;
+  [[maybe_unused]] const bool hx_dyn = HX && a.in_amax != nullptr;
+  if constexpr (HX) {
+    if (hx_dyn) hx_dynamic_scale(a.in_amax[b], hx_in, hx_out);
+  }
   float preg[C::ITEMS][8];
   auto chunk_kz_c0 = [&](int ch, int& kz, int& c0) {
     const int kzi = ch / n_cc;
@@ -185,7 +191,8 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
       }
       if constexpr (HX) {
         uint4 ph, pl;
-        split2(v, ph, pl);
+        if (hx_dyn) split2_scaled(v, hx_in, ph, pl);           // (uniform branch: one image per workgroup)
+        else split2(v, ph, pl);
         st[it_lds[i]] = ph;
         st[2 * C::PLANE + it_lds[i]] = pl;
       } else {
@@ -353,8 +360,8 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + (wco * NCT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      bv[m][r] = bias_p[has_bias ? (co < a.Cout ? co : a.Cout - 1) : 0];
-      if constexpr (HX) sv[m][r] = scale_p[co < n_ct * 32 ? co : 0];
+      bv[m][r] = bias_p[has_bias ? b * a.bias_bstride + (co < a.Cout ? co : a.Cout - 1) : 0];
+      if constexpr (HX) sv[m][r] = scale_p[co < n_ct * 32 ? co : 0] * hx_out;
     }
   constexpr int NBATCH = NPT * NCT;
   float rv[2][16];
@@ -414,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
           }
           if (has_bias) v += bv[m][r];
           if (has_res) v += rv[q & 1][r];
+          v *= a.out_scale;
           if (a.out) a.out[o] = v;
           if (a.out_act) a.out_act[o] = a.act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, a.act_out);
         }
@@ -494,12 +502,13 @@ __global__ __launch_bounds__(256) void bx3_splitk_reduce_kernel(const float* __r
                                                                 const float* __restrict__ bias,
                                                                 const float* __restrict__ residual, float* out,
                                                                 float* out_act, int act_out, int Cout, int64_t plane,
-                                                                int64_t total) {
+                                                                int64_t total, int bias_bstride, float out_scale) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     float v = partial[i];
     for (int s = 1; s < ksplit; ++s) v += partial[(size_t)s * total + i];
-    if (bias) v += bias[(i / plane) % Cout];
+    if (bias) v += bias[(i / (plane * Cout)) * bias_bstride + (i / plane) % Cout];
     if (residual) v += residual[i];
+    v *= out_scale;
     if (out) out[i] = v;
     if (out_act) out_act[i] = act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, act_out);
   }
@@ -629,7 +638,7 @@ extern "C" int ipdm_conv_bx3_pack_weight(const float* w, void* packed, int Cout,
 
 static int conv3d_bx3_entry(const float* x, const void* wq, const float* bias, const float* coef, int act,
                             const float* residual, float* out, float* out_act, int act_out, int B, int Cin, int Cout, int D,
-                            int H, int W, int k, int dilation, void* stream, int hx) {
+                            int H, int W, int k, int dilation, void* stream, int hx, const ipdm_conv_ext_t* ext = nullptr) {
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0 && (k == 1 || k == 3) && dilation >= 1);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && wq && (out || out_act) && x != out && x != out_act);
@@ -640,20 +649,22 @@ static int conv3d_bx3_entry(const float* x, const void* wq, const float* bias, c
   a.D = D; a.kd = k;
   a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
   a.hx = hx;
+  conv_apply_ext(a, ext, hx);
   return conv_bx3_dispatch(a, k, ipdm_stream(stream));
 }
 
 extern "C" int ipdm_conv3d_bx3_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
                                    const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
-                                   int Cout, int D, int H, int W, int k, int dilation, void* stream) {
-  return conv3d_bx3_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, D, H, W, k, dilation, stream, 0);
+                                   int Cout, int D, int H, int W, int k, int dilation, const ipdm_conv_ext_t* ext, void* stream) {
+  return conv3d_bx3_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, D, H, W, k, dilation, stream, 0, ext);
 }
 
 /* f16x2 forms (conv_kernel.h): same arguments, wq from ipdm_conv_hx2_pack_weight */
 extern "C" int ipdm_conv3d_hx2_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
                                    const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
-                                   int Cout, int D, int H, int W, int k, int dilation, void* stream) {
-  return conv3d_bx3_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, D, H, W, k, dilation, stream, 1);
+                                   int Cout, int D, int H, int W, int k, int dilation, const ipdm_conv_ext_t* ext, void* stream) {
+  return conv3d_bx3_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, D, H, W, k, dilation, stream, 1,
+                          ext);
 }
 
 extern "C" int ipdm_conv_bx3_splitk(int B, int D, int Cin, int Cout, int H, int W, int k, int dilation) {
@@ -665,7 +676,7 @@ extern "C" int ipdm_conv_bx3_splitk(int B, int D, int Cin, int Cout, int H, int 
 static int conv_bx3_splitk_entry(const float* x, const void* wq, const float* bias, const float* coef, int act,
                                  const float* residual, float* out, float* out_act, int act_out, int B, int Cin, int Cout,
                                  int D, int H, int W, int k, int dilation, int volume, int ksplit, float* work, void* stream,
-                                 int hx) {
+                                 int hx, const ipdm_conv_ext_t* ext = nullptr) {
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0 && (k == 1 || k == 3) && dilation >= 1);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && wq && work && ksplit > 1 && (out || out_act) && x != out && x != out_act);
@@ -677,33 +688,37 @@ static int conv_bx3_splitk_entry(const float* x, const void* wq, const float* bi
   a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = nullptr;
   a.ksplit = ksplit; a.partial = work;
   a.hx = hx;
+  conv_apply_ext(a, ext, hx);
+  const float out_scale = a.out_scale;
+  a.out_scale = 1.f;                            // the parts are raw partial sums; the reduce pass applies bias / residual / scale
   int rc = conv_bx3_dispatch(a, k, ipdm_stream(stream));
+  a.out_scale = out_scale;
   if (rc != IPDM_OK) return rc;
   const int64_t plane = (int64_t)D * H * W, total = (int64_t)B * Cout * plane;
   hipLaunchKernelGGL(bx3_splitk_reduce_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, ipdm_stream(stream), work, ksplit,
-                     bias, residual, out, out_act, act_out, Cout, (long long)plane, (long long)total);
+                     bias, residual, out, out_act, act_out, Cout, (long long)plane, (long long)total, a.bias_bstride, a.out_scale);
   return ipdm_launch_status();
 }
 
 extern "C" int ipdm_conv_bx3_splitk_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
                                         const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
                                         int Cout, int D, int H, int W, int k, int dilation, int volume, int ksplit,
-                                        float* work, void* stream) {
+                                        float* work, const ipdm_conv_ext_t* ext, void* stream) {
   return conv_bx3_splitk_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, D, H, W, k, dilation, volume,
-                               ksplit, work, stream, 0);
+                               ksplit, work, stream, 0, ext);
 }
 
 extern "C" int ipdm_conv_hx2_splitk_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
                                         const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
                                         int Cout, int D, int H, int W, int k, int dilation, int volume, int ksplit,
-                                        float* work, void* stream) {
+                                        float* work, const ipdm_conv_ext_t* ext, void* stream) {
   return conv_bx3_splitk_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, D, H, W, k, dilation, volume,
-                               ksplit, work, stream, 1);
+                               ksplit, work, stream, 1, ext);
 }
 
 static int conv2d_bx3_entry(const float* x, const void* wq, const float* bias, const float* coef, int act,
                             const float* residual, float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H,
-                            int W, int k, int dilation, void* stream, int hx) {
+                            int W, int k, int dilation, void* stream, int hx, const ipdm_conv_ext_t* ext = nullptr) {
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (k == 1 || k == 3) && dilation >= 1);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && wq && (out || out_act) && x != out && x != out_act);
@@ -714,17 +729,19 @@ static int conv2d_bx3_entry(const float* x, const void* wq, const float* bias, c
   a.D = 1; a.kd = 1;
   a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
   a.hx = hx;
+  conv_apply_ext(a, ext, hx);
   return conv_bx3_dispatch(a, k, ipdm_stream(stream));
 }
 
 extern "C" int ipdm_conv2d_bx3_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
                                    const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
-                                   int Cout, int H, int W, int k, int dilation, void* stream) {
-  return conv2d_bx3_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, H, W, k, dilation, stream, 0);
+                                   int Cout, int H, int W, int k, int dilation, const ipdm_conv_ext_t* ext, void* stream) {
+  return conv2d_bx3_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, H, W, k, dilation, stream, 0, ext);
 }
 
 extern "C" int ipdm_conv2d_hx2_f32(const float* x, const void* wq, const float* bias, const float* coef, int act,
                                    const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
-                                   int Cout, int H, int W, int k, int dilation, void* stream) {
-  return conv2d_bx3_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, H, W, k, dilation, stream, 1);
+                                   int Cout, int H, int W, int k, int dilation, const ipdm_conv_ext_t* ext, void* stream) {
+  return conv2d_bx3_entry(x, wq, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, H, W, k, dilation, stream, 1,
+                          ext);
 }

@@ -68,6 +68,23 @@ __device__ __forceinline__ void split2_pk_scaled(float v0, float v1, float s, un
 }
 constexpr float HX_WINO_PRESCALE = 0.25f;
 
+// per-image DYNAMIC input scale (ConvArgs.in_amax: max |x| of every image, from ipdm_absmax_f32): the power of two s with
+// amax * s in [2^14, 2^15) -- fp16's range then fits ANY fp32 input (the scale and its inverse are exact), and values down to
+// 2^-17 of the image's maximum keep all 22 bits.  -> (s, 1 / s); amax zero / denormal / non-finite -> (1, 1).
+__device__ __forceinline__ void hx_dynamic_scale(float amax, float& s, float& inv_s) {
+  const unsigned e = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;     // amax in [2^(e-127), 2^(e-126))
+  const bool ok = e >= 15u && e <= 253u;                                     // keeps both exponent fields in [1, 254]
+  s = __builtin_bit_cast(float, ok ? (268u - e) << 23 : 0x3f800000u);        // 2^(141 - e)
+  inv_s = __builtin_bit_cast(float, ok ? (e - 14u) << 23 : 0x3f800000u);     // 2^(e - 141)
+}
+// split2 with a power-of-two pre-scale (direct kernel, dynamic range)
+__device__ __forceinline__ void split2_scaled(const float (&v)[8], float s, uint4& h, uint4& l) {
+  split2_pk_scaled(v[0], v[1], s, h.x, l.x);
+  split2_pk_scaled(v[2], v[3], s, h.y, l.y);
+  split2_pk_scaled(v[4], v[5], s, h.z, l.z);
+  split2_pk_scaled(v[6], v[7], s, h.w, l.w);
+}
+
 // eight consecutive k values -> the hi and the lo MFMA operand
 __device__ __forceinline__ void split2(const float (&v)[8], uint4& h, uint4& l) {
   split2_pk(v[0], v[1], h.x, l.x);
@@ -104,6 +121,11 @@ struct ConvArgs {
                              //   layers.py:291-313) to out / out_act [B][Cout][H/2][W/2]; residual is at that size too
   int ksplit = 1;            // conv_bx3 only: the K (input channel x depth tap) chunks are dealt to ksplit workgroups
   float* partial = nullptr;  //   per tile, each writing its raw partial sums to partial[ks][B][Cout][D*H*W]
+  int bias_bstride = 0;      // split-operand kernels: bias index = image * bias_bstride + channel (Cout: one bias row per image, e.g.
+                             //   conv bias + the time-embedding shift of a score_sde block; 0: the usual per-channel bias)
+  float out_scale = 1.f;     //   ... and result = (conv + bias + residual) * out_scale (score_sde skip_rescale: 1 / sqrt 2)
+  const float* in_amax = nullptr;   // f16x2 only: per-image max |x| [B] (ipdm_absmax_f32) -> per-image power-of-two input scale
+                                    //   (hx_dynamic_scale); NULL: static range contract |x| < 65504
   int hx = 0;                // conv_bx3 / conv_wino_bx3: 1 = the weights are an f16x2 blob (two fp16 pieces + per-channel inverse
                              //   scales), run the three-MFMA fp16 instantiation
   float* stats = nullptr;    // conv_wino_bx3 wide kernel (16 x 4 tile block, 16-byte DMA) only: per-plane statistics of
@@ -112,12 +134,19 @@ struct ConvArgs {
                              //   InstanceNorm++ needs, so that it does not read the tensor again
 };
 
-// split-K second pass (conv_bx3.hip): out = bias + sum_s partial[s] (fixed order) + residual; out_act = act_out(out)
+// split-K second pass (conv_bx3.hip): out = (bias + sum_s partial[s] (fixed order) + residual) * out_scale; out_act = act_out(out)
 __global__ __launch_bounds__(256) void bx3_splitk_reduce_kernel(const float* __restrict__ partial, int ksplit,
                                                                 const float* __restrict__ bias,
                                                                 const float* __restrict__ residual, float* out,
                                                                 float* out_act, int act_out, int Cout, int64_t plane,
-                                                                int64_t total);
+                                                                int64_t total, int bias_bstride, float out_scale);
+
+// optional extras of the split-operand entry points (include/ipdm.h: ipdm_conv_ext_t) -> ConvArgs
+inline void conv_apply_ext(ConvArgs& a, const ipdm_conv_ext_t* ext, int hx) {
+  a.in_amax = hx && ext ? ext->in_amax : nullptr;
+  a.bias_bstride = ext ? ext->bias_bstride : 0;
+  a.out_scale = ext && ext->out_scale != 0.f ? ext->out_scale : 1.f;
+}
 
 // NCT x NPT MFMA tiles per wave, WCO x WPX waves (WCO*WPX == 4), PW = pixel-tile width (16 or 32),
 // DMAX = largest dilation the LDS patch is sized for, KC = input channels per chunk, KS = 1 or 3.

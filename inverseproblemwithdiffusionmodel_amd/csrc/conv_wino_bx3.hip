@@ -198,6 +198,17 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.x), 0, (int)((size_t)a.B * a.Cin * HW * 4), 0x00020000);
 
+  // f16x2: input pre-scale (1/4 for the transform's growth, times the image's dynamic scale when a.in_amax is given) and what
+  // the epilogue multiplies by besides the weight scale
+  [[maybe_unused]] float hx_in = HX_WINO_PRESCALE, hx_out = 1.f;
+  if constexpr (HX) {
+    if (a.in_amax) {
+      float sd, si;
+      hx_dynamic_scale(a.in_amax[b], sd, si);
+      hx_in = HX_WINO_PRESCALE * sd;
+      hx_out = si;
+    }
+  }
   float dreg[16];
   auto load_patch = [&](int ci) {                            // ci: absolute input channel (wave-uniform)
     const int soff = (int)(((size_t)b * a.Cin + ci) * HW * 4);
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
                              tmp[r * 4 + 1] - tmp[r * 4 + 3]};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const float vsc = v4[c] * HX_WINO_PRESCALE;         // exact; undone by the inverse weight scale
+          const float vsc = v4[c] * hx_in;                    // exact (power of two); undone in the epilogue
           const _Float16 hi = (_Float16)vsc;
           const _Float16 lo = (_Float16)(vsc - (float)hi);
           vs[((r * 4 + c) * 2 + 0) * (X_KC * X_TILES)] = hi;
@@ -470,8 +481,8 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int co = co0 + c * 32 + cg * 4 + i;
-      bv[c][i] = bias_p[has_bias ? co : 0];
-      sv[c][i] = scale_p[HX ? co : 0];
+      bv[c][i] = bias_p[has_bias ? b * a.bias_bstride + co : 0];
+      sv[c][i] = scale_p[HX ? co : 0] * hx_out;
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) {
         const size_t o = res_ok ? ((size_t)b * a.Cout + co) * HW + (size_t)(oy + (SMALL ? d * ii : ii)) * a.W + ox : 0;
@@ -528,6 +539,8 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
             y0v += rv[c][i][ii].x;
             y1v += rv[c][i][ii].y;
           }
+          y0v *= a.out_scale;
+          y1v *= a.out_scale;
           if constexpr (SMALL) {
             if (a.out) {
               a.out[o] = y0v;
@@ -829,12 +842,27 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       v[rr * 4 + 3] = tmp[rr * 4 + 1] - tmp[rr * 4 + 3];
     }
   };
+  // hx_in: the input pre-scale of the image whose chunk is being staged (1/4 for the transform's growth x the image's dynamic
+  // scale, or just 1/4); hx_out: what the epilogue multiplies the current tile's result by besides the weight scale
+  [[maybe_unused]] float hx_in = HX_WINO_PRESCALE, hx_out = 1.f;
+  auto hx_scales_of = [&](int b, float& s_in, float& s_out) {
+    s_in = HX_WINO_PRESCALE;
+    s_out = 1.f;
+    if constexpr (HX) {
+      if (a.in_amax) {
+        float sd, si;
+        hx_dynamic_scale(a.in_amax[b], sd, si);
+        s_in = HX_WINO_PRESCALE * sd;
+        s_out = si;
+      }
+    }
+  };
   auto store_pair = [&](float* st, const float (&va)[16], const float (&vb)[16], auto p_lo, auto p_hi) {
     unsigned* vs = reinterpret_cast<unsigned*>(st) + wave * X_TILES + mytile;
 #pragma unroll
     for (int p = decltype(p_lo)::value; p < decltype(p_hi)::value; ++p) {
       unsigned hp, lp;
-      split2_pk_scaled(va[p], vb[p], HX_WINO_PRESCALE, hp, lp);
+      split2_pk_scaled(va[p], vb[p], hx_in, hp, lp);
       vs[(p * 2 + 0) * (8 * X_TILES)] = hp;
       vs[(p * 2 + 1) * (8 * X_TILES)] = lp;
     }
@@ -891,6 +919,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   Geo cur_g = geo_of(tile);
   uint4 afr[2][2][NPC];
   load_A(afr[0], p0, cur_g.c0, cur_g.co_tile);
+  hx_scales_of(cur_g.b, hx_in, hx_out);
   set_dma_geo(cur_g);
   // workgroup barrier for LDS data only: __syncthreads() also drains vmcnt, i.e. would wait for a DMA just issued
   auto lds_barrier = [&]() {
@@ -935,6 +964,10 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       const bool a_next = ch + 1 >= n_chunks;
       const int a_chunk = a_next ? next_g.c0 : cur_g.c0 + ch + 1;
       const int a_cot = a_next ? next_g.co_tile : cur_g.co_tile;
+      if constexpr (HX) {
+        [[maybe_unused]] float unused_out;
+        if (a_next) hx_scales_of(next_g.b, hx_in, unused_out);    // this chunk stages chunk 0 of the NEXT tile (its image's scale)
+      }
       if constexpr (WPRIV) {
         // this wave's DMA of chunk c+1 (issued a chunk ago) and the fragments of position p0 have landed: fragments of position
         // p0+1 first (older than the next DMA in the in-order vmcnt queue), the wave's own patches into registers, and at once
@@ -1165,8 +1198,8 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       const bool res_ok = has_res && in_range(tg);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        biasv[bf][i] = bias_p[has_bias ? co0 + c * 32 + ecg * 2 + i : 0];
-        if constexpr (HX) scalev[bf][i] = scale_p[co0 + c * 32 + ecg * 2 + i];
+        biasv[bf][i] = bias_p[has_bias ? cur_g.b * a.bias_bstride + co0 + c * 32 + ecg * 2 + i : 0];
+        if constexpr (HX) scalev[bf][i] = scale_p[co0 + c * 32 + ecg * 2 + i] * hx_out;
 #pragma unroll
         for (int ii = 0; ii < NR; ++ii) {
           const size_t o = res_ok ? out_index(c, tg, i, ii) : 0;
@@ -1227,6 +1260,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
             float v = (((y00 + y10) + y01) + y11) * 0.25f;
             const size_t o = out_index(c, tg, i, 0);
             if (has_res) v += resv[bf][i][0].x;
+            v *= a.out_scale;
             if constexpr (STATS) sv[i][0] = v;
             if (a.out) a.out[o] = v;
             if (a.out_act) a.out_act[o] = a.act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, a.act_out);
@@ -1246,6 +1280,8 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
               y0v += resv[bf][i][ii].x;
               y1v += resv[bf][i][ii].y;
             }
+            y0v *= a.out_scale;
+            y1v *= a.out_scale;
             if constexpr (STATS) {
               sv[i][2 * ii] = y0v;
               sv[i][2 * ii + 1] = y1v;
@@ -1313,6 +1349,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     zero_acc();
     tile = next_tile;
     cur_g = next_g;
+    hx_scales_of(cur_g.b, hx_in, hx_out);
   }
   if (a.dbg) {
     __builtin_amdgcn_s_waitcnt(0);
@@ -1516,6 +1553,8 @@ static int conv_wino_bx3_launch_ksplit_t(ConvArgs a, int ksplit, float* work, hi
   a.co_tiles = a.Cout / X_CO;
   a.ksplit = ksplit;
   a.bias = nullptr; a.residual = nullptr; a.out_act = nullptr; a.out = work; a.pool2 = 0; a.stats = nullptr;
+  const float out_scale = a.out_scale;
+  a.out_scale = 1.f;                              // the parts are raw sums: bias / residual / scale belong to the reduce pass
   const int64_t nblk = (int64_t)a.B * a.tiles_x * a.tiles_y * a.co_tiles * ksplit;
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
   static bool attr_set = false;
@@ -1530,7 +1569,7 @@ static int conv_wino_bx3_launch_ksplit_t(ConvArgs a, int ksplit, float* work, hi
                      X_LDS_BYTES, s, a, (int)nblk);
   const int64_t plane = (int64_t)a.H * a.W, total = (int64_t)a.B * a.Cout * plane;
   hipLaunchKernelGGL(bx3_splitk_reduce_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, s, work, ksplit, bias, residual,
-                     out, out_act, a.act_out, a.Cout, plane, total);
+                     out, out_act, a.act_out, a.Cout, plane, total, a.bias_bstride, out_scale);
   return ipdm_launch_status();
 }
 
@@ -1589,7 +1628,7 @@ extern "C" int ipdm_conv2d_wino_bx3_supported(int Cin, int Cout, int H, int W, i
 
 static int wino_bx3_entry(const float* x, const void* U, const float* bias, const float* residual, float* out,
                           float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation, int pool2,
-                          float* stats, void* stream, int hx = 0) {
+                          float* stats, void* stream, int hx = 0, const ipdm_conv_ext_t* ext = nullptr) {
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && dilation >= 1);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && U && (out || out_act) && x != out && x != out_act);
@@ -1600,14 +1639,15 @@ static int wino_bx3_entry(const float* x, const void* U, const float* bias, cons
   a.pool2 = pool2 ? 1 : 0;
   a.stats = stats;
   a.hx = hx;
+  conv_apply_ext(a, ext, hx);
   if (!wino_bx3_ok(a, 3)) return IPDM_EUNSUPPORTED;
   return conv_wino_bx3_launch(a, ipdm_stream(stream));
 }
 
 extern "C" int ipdm_conv2d_wino_bx3_f32(const float* x, const void* U, const float* bias, const float* residual,
                                         float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H, int W,
-                                        int dilation, int pool2, void* stream) {
-  return wino_bx3_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, pool2, nullptr, stream);
+                                        int dilation, int pool2, const ipdm_conv_ext_t* ext, void* stream) {
+  return wino_bx3_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, pool2, nullptr, stream, 0, ext);
 }
 
 /* Split-K form for 16-pixel layers with fewer than 512 output channels: ipdm_conv2d_wino_bx3_splitk returns the number of K
@@ -1622,7 +1662,7 @@ extern "C" int ipdm_conv2d_wino_bx3_splitk(int Cin, int Cout, int H, int W, int 
 
 static int wino_bx3_splitk_entry(const float* x, const void* U, const float* bias, const float* residual, float* out,
                                  float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation, int ksplit,
-                                 float* work, void* stream, int hx) {
+                                 float* work, void* stream, int hx, const ipdm_conv_ext_t* ext = nullptr) {
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && dilation >= 1 && ksplit >= 2);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && U && work && (out || out_act) && x != out && x != out_act);
@@ -1631,28 +1671,32 @@ static int wino_bx3_splitk_entry(const float* x, const void* U, const float* bia
   a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = dilation; a.act = IPDM_ACT_NONE;
   a.D = 1; a.kd = 1; a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = nullptr;
   a.hx = hx;
+  conv_apply_ext(a, ext, hx);
   if (!wino_bx3_ok(a, 3)) return IPDM_EUNSUPPORTED;
   return conv_wino_bx3_launch_ksplit(a, ksplit, work, ipdm_stream(stream));
 }
 
 extern "C" int ipdm_conv2d_wino_bx3_splitk_f32(const float* x, const void* U, const float* bias, const float* residual,
                                                float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H,
-                                               int W, int dilation, int ksplit, float* work, void* stream) {
-  return wino_bx3_splitk_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, ksplit, work, stream, 0);
+                                               int W, int dilation, int ksplit, float* work, const ipdm_conv_ext_t* ext, void* stream) {
+  return wino_bx3_splitk_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, ksplit, work, stream, 0, ext);
 }
 
 /* f16x2 forms of the three calls above: same arguments, U from ipdm_conv_wino_hx2_pack_weight (conv_kernel.h: two fp16
  * pieces, three MFMAs per product; the shape rules -- _supported, _splitk, _stats_partials -- are shared) */
 extern "C" int ipdm_conv2d_wino_hx2_f32(const float* x, const void* U, const float* bias, const float* residual,
                                         float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H, int W,
-                                        int dilation, int pool2, void* stream) {
-  return wino_bx3_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, pool2, nullptr, stream, 1);
+                                        int dilation, int pool2, const ipdm_conv_ext_t* ext, void* stream) {
+  return wino_bx3_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, pool2, nullptr, stream, 1,
+                        ext);
 }
 
 extern "C" int ipdm_conv2d_wino_hx2_splitk_f32(const float* x, const void* U, const float* bias, const float* residual,
                                                float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H,
-                                               int W, int dilation, int ksplit, float* work, void* stream) {
-  return wino_bx3_splitk_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, ksplit, work, stream, 1);
+                                               int W, int dilation, int ksplit, float* work, const ipdm_conv_ext_t* ext,
+                                               void* stream) {
+  return wino_bx3_splitk_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, ksplit, work, stream, 1,
+                               ext);
 }
 
 // partials per plane the statistics epilogue writes for this layer shape (0: that epilogue does not serve it)
@@ -1667,16 +1711,18 @@ extern "C" int ipdm_conv2d_wino_bx3_stats_partials(int Cin, int Cout, int H, int
 
 extern "C" int ipdm_conv2d_wino_bx3_stats_f32(const float* x, const void* U, const float* bias, const float* residual,
                                               float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H,
-                                              int W, int dilation, int pool2, float* stats, void* stream) {
+                                              int W, int dilation, int pool2, float* stats, const ipdm_conv_ext_t* ext, void* stream) {
   IPDM_REQUIRE(stats != nullptr);
   if (ipdm_conv2d_wino_bx3_stats_partials(Cin, Cout, H, W, dilation, pool2) == 0) return IPDM_EUNSUPPORTED;
-  return wino_bx3_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, pool2, stats, stream);
+  return wino_bx3_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, pool2, stats, stream, 0, ext);
 }
 
 extern "C" int ipdm_conv2d_wino_hx2_stats_f32(const float* x, const void* U, const float* bias, const float* residual,
                                               float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H,
-                                              int W, int dilation, int pool2, float* stats, void* stream) {
+                                              int W, int dilation, int pool2, float* stats, const ipdm_conv_ext_t* ext,
+                                              void* stream) {
   IPDM_REQUIRE(stats != nullptr);
   if (ipdm_conv2d_wino_bx3_stats_partials(Cin, Cout, H, W, dilation, pool2) == 0) return IPDM_EUNSUPPORTED;
-  return wino_bx3_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, pool2, stats, stream, 1);
+  return wino_bx3_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, dilation, pool2, stats, stream, 1,
+                        ext);
 }

@@ -53,10 +53,14 @@ __global__ __launch_bounds__(256) void groupnorm_coef_kernel(const float* __rest
 //   gn_combine_kernel:  one workgroup per (image, group): equal-sized planes combine exactly as
 //       mean_g = avg(mean_c),  M2_g = sum M2_c + HW * sum (mean_c - mean_g)^2   (Chan et al.)
 // against (B x G) workgroups sweeping (C/G)*HW elements twice in groupnorm_coef_kernel (kept for larger planes).
+// (c_src, c_tot, c_off): the planes of `x` are channels c_off .. c_off + c_src - 1 of a (virtual) tensor of c_tot channels whose
+// coefficients `coef` holds -- GroupNorm over torch.cat([x1, x2], dim=1) without the concatenation; (C, C, 0) otherwise
 template <int T>
-__global__ __launch_bounds__(T) void gn_plane_kernel(const float* __restrict__ x, float* __restrict__ coef, int HW) {
+__global__ __launch_bounds__(T) void gn_plane_kernel(const float* __restrict__ x, float* __restrict__ coef, int HW, int c_src,
+                                                     int c_tot, int c_off) {
   __shared__ double red[T / 64];
   const float* p = x + (size_t)blockIdx.x * HW;
+  const size_t slot = (size_t)(blockIdx.x / c_src) * c_tot + c_off + blockIdx.x % c_src;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n4 = HW / 4;
   float4 keep[16];
@@ -92,8 +96,8 @@ __global__ __launch_bounds__(T) void gn_plane_kernel(const float* __restrict__ x
     double m2 = 0.0;
 #pragma unroll
     for (int w = 0; w < T / 64; ++w) m2 += red[w];
-    coef[(size_t)blockIdx.x * 3 + 0] = mean;
-    coef[(size_t)blockIdx.x * 3 + 1] = (float)m2;
+    coef[slot * 3 + 0] = mean;
+    coef[slot * 3 + 1] = (float)m2;
   }
 }
 
@@ -260,14 +264,36 @@ extern "C" int ipdm_groupnorm_coef_f32(const float* x, const float* weight, cons
   IPDM_REQUIRE(x && coef);
   if (HW % 4 == 0 && HW <= 65536 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     if (HW <= 16384)
-      hipLaunchKernelGGL(gn_plane_kernel<256>, dim3(B * C), dim3(256), 0, ipdm_stream(stream), x, coef, HW);
+      hipLaunchKernelGGL(gn_plane_kernel<256>, dim3(B * C), dim3(256), 0, ipdm_stream(stream), x, coef, HW, C, C, 0);
     else
-      hipLaunchKernelGGL(gn_plane_kernel<1024>, dim3(B * C), dim3(1024), 0, ipdm_stream(stream), x, coef, HW);
+      hipLaunchKernelGGL(gn_plane_kernel<1024>, dim3(B * C), dim3(1024), 0, ipdm_stream(stream), x, coef, HW, C, C, 0);
     hipLaunchKernelGGL(gn_combine_kernel, dim3(B * G), dim3(64), 0, ipdm_stream(stream), weight, bias, coef, C, HW, G, eps);
     return ipdm_launch_status();
   }
   hipLaunchKernelGGL(groupnorm_coef_kernel, dim3(B * G), dim3(256), 0, ipdm_stream(stream), x, weight, bias, coef, C, HW,
                      G, eps);
+  return ipdm_launch_status();
+}
+
+// GroupNorm coefficients of torch.cat([x1, x2], dim=1) without the concatenation (single-read plane kernels only: planes of
+// whole float4s up to 256 x 256; IPDM_EUNSUPPORTED otherwise -- the caller concatenates and uses ipdm_groupnorm_coef_f32)
+extern "C" int ipdm_groupnorm_coef_cat_f32(const float* x1, int C1, const float* x2, int C2, const float* weight,
+                                           const float* bias, float* coef, int B, int HW, int G, float eps, void* stream) {
+  const int C = C1 + C2;
+  IPDM_REQUIRE(B >= 0 && C1 > 0 && C2 > 0 && HW > 0 && G > 0 && C % G == 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x1 && x2 && coef);
+  if (!(HW % 4 == 0 && HW <= 65536 && ((reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(x2)) & 15) == 0))
+    return IPDM_EUNSUPPORTED;
+  hipStream_t s = ipdm_stream(stream);
+  if (HW <= 16384) {
+    hipLaunchKernelGGL(gn_plane_kernel<256>, dim3(B * C1), dim3(256), 0, s, x1, coef, HW, C1, C, 0);
+    hipLaunchKernelGGL(gn_plane_kernel<256>, dim3(B * C2), dim3(256), 0, s, x2, coef, HW, C2, C, C1);
+  } else {
+    hipLaunchKernelGGL(gn_plane_kernel<1024>, dim3(B * C1), dim3(1024), 0, s, x1, coef, HW, C1, C, 0);
+    hipLaunchKernelGGL(gn_plane_kernel<1024>, dim3(B * C2), dim3(1024), 0, s, x2, coef, HW, C2, C, C1);
+  }
+  hipLaunchKernelGGL(gn_combine_kernel, dim3(B * G), dim3(64), 0, s, weight, bias, coef, C, HW, G, eps);
   return ipdm_launch_status();
 }
 

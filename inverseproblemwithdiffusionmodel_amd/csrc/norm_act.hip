@@ -207,6 +207,31 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* x, const f
   }
 }
 
+// affine + activation of torch.cat([x1, x2], dim=1) without the concatenation: plane (b, c) of the output reads channel c of x1
+// (c < C1) or channel c - C1 of x2; the output IS the concatenated, normalised tensor (written once)
+__global__ __launch_bounds__(256) void affine_act_cat_kernel(const float* x1, int C1, const float* x2, int C2,
+                                                             const float* __restrict__ coef, float* y, int HW, int act) {
+  const size_t plane = blockIdx.y;
+  const int Ct = C1 + C2;
+  const size_t b = plane / Ct;
+  const int c = (int)(plane % Ct);
+  const float mu = coef[plane * 3], sc = coef[plane * 3 + 1], sh = coef[plane * 3 + 2];
+  const float* p = c < C1 ? x1 + (b * C1 + c) * HW : x2 + (b * C2 + (c - C1)) * HW;
+  float* o = y + plane * HW;
+  if ((HW & 3) == 0) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW / 4; i += gridDim.x * 256) {
+      float4 v = reinterpret_cast<const float4*>(p)[i];
+      v.x = ipdm_act((v.x - mu) * sc + sh, act);
+      v.y = ipdm_act((v.y - mu) * sc + sh, act);
+      v.z = ipdm_act((v.z - mu) * sc + sh, act);
+      v.w = ipdm_act((v.w - mu) * sc + sh, act);
+      reinterpret_cast<float4*>(o)[i] = v;
+    }
+  } else {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) o[i] = ipdm_act((p[i] - mu) * sc + sh, act);
+  }
+}
+
 // ---- generic element-wise -------------------------------------------------------------------
 template <typename F>
 __global__ __launch_bounds__(256) void ew1_kernel(const float* x, float* y, int64_t n, F f) {
@@ -460,6 +485,20 @@ extern "C" int ipdm_affine_act_f32(const float* x, const float* coef, float* y, 
     hipLaunchKernelGGL(affine_act_kernel, dim3(gx, np), dim3(256), 0, ipdm_stream(stream), x + p0 * HW, coef + p0 * 3,
                        y + p0 * HW, HW, act);
   }
+  return ipdm_launch_status();
+}
+
+extern "C" int ipdm_affine_act_cat_f32(const float* x1, int C1, const float* x2, int C2, const float* coef, float* y, int B,
+                                       int HW, int act, void* stream) {
+  IPDM_REQUIRE(B >= 0 && C1 > 0 && C2 > 0 && HW > 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x1 && x2 && coef && y && y != x1 && y != x2);
+  const int64_t planes = (int64_t)B * (C1 + C2);
+  if (planes > 65535) return IPDM_EUNSUPPORTED;                // one grid.y; the networks here stay far below it
+  int gx = (HW / 4 + 255) / 256;
+  gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+  hipLaunchKernelGGL(affine_act_cat_kernel, dim3(gx, (unsigned)planes), dim3(256), 0, ipdm_stream(stream), x1, C1, x2, C2, coef,
+                     y, HW, act);
   return ipdm_launch_status();
 }
 

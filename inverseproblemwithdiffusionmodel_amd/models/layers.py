@@ -56,15 +56,44 @@ class Conv(ops.PackedWeightMixin, nn.Module):
         impl = ops.impl_unbounded()
         return self._cache.get(self.weight, "wino_" + impl, lambda w: ops.conv_wino_split_weight(w, impl))
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, bounded=False, bias_rows=None, out_scale=1.0):
+        """bounded: x is act(GroupNorm(.)) (possibly FIR-resampled) -- |x| <= |gamma| sqrt(group size) + |beta|, inside the
+        f16x2 family's static range; otherwise (raw skip / pyramid / input streams) the convolution measures its input and
+        runs with the dynamic range (ops.unbounded_amax).
+        bias_rows [B, Cout]: replaces the bias by one row per image (the caller has added self.bias into it);
+        out_scale: result = (conv + bias + residual) * out_scale -- both folded into the epilogue (split families only)."""
+        amax = None if bounded else ops.unbounded_amax()
         bias = None if self.bias is None else self.bias.data
+        if bias_rows is not None:
+            bias = bias_rows
         if (self.kernel_size == 3 and self.dilation == 1 and residual is None and min(self.in_planes, self.out_planes) <= 3
                 and ops.conv3x3_thin_ok(self.in_planes, self.out_planes, x.shape[2], x.shape[3])):
             return ops.conv3x3_thin(x, self.weight.data, bias)         # first / last layer: streaming kernels
         if (ops.impl_unbounded() in ops.SPLIT_IMPLS and self.kernel_size == 3
                 and ops.wino_bx3_pays(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation)):
-            return ops.conv2d_wino_bx3(x, self.packed_wino(), bias, residual, dilation=self.dilation)
-        return ops.conv2d(x, self.packed(), bias, residual=residual, dilation=self.dilation)
+            return ops.conv2d_wino_bx3(x, self.packed_wino(), bias, residual, dilation=self.dilation, in_amax=amax,
+                                       out_scale=out_scale)
+        return ops.conv2d(x, self.packed(), bias, residual=residual, dilation=self.dilation, in_amax=amax, out_scale=out_scale)
+
+    def epilogue_folds(self):
+        """True when per-image bias rows / out_scale can ride in this convolution's epilogue (split-operand kernels)"""
+        return ops.impl_unbounded() in ops.SPLIT_IMPLS and not (self.kernel_size == 3 and min(self.in_planes, self.out_planes) <= 3)
+
+    def forward_parts(self, xs, residual=None, out_scale=1.0):
+        """the convolution of torch.cat(xs, dim=1) WITHOUT the concatenation: sum_i conv(xs[i], weight[:, slice_i]), each part
+        taking the previous sum as its residual (the bias rides with the first, out_scale with the last).  1x1 kernels."""
+        assert self.kernel_size == 1 and sum(t.shape[1] for t in xs) == self.in_planes
+        impl = ops.impl_unbounded()
+        acc, c0 = residual, 0
+        for i, t in enumerate(xs):
+            c1 = c0 + t.shape[1]
+            packed = self._cache.get(self.weight, f"direct_{impl}_{c0}_{c1}",
+                                     lambda w, a=c0, b=c1: ops.conv_weight(w[:, a:b].contiguous(), impl))
+            last = i == len(xs) - 1
+            acc = ops.conv2d(t, packed, self.bias.data if (i == 0 and self.bias is not None) else None, residual=acc,
+                             in_amax=ops.unbounded_amax(), out_scale=out_scale if last else 1.0)
+            c0 = c1
+        return acc
 
 
 def ddpm_conv1x1(in_planes, out_planes, stride=1, bias=True, init_scale=1., padding=0):
@@ -113,6 +142,8 @@ class GroupNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(num_channels))
 
     def forward(self, x, act=ops.ACT_NONE):
+        if isinstance(x, (tuple, list)):        # GroupNorm(+act) of torch.cat(x, dim=1) without the concatenation
+            return ops.groupnorm_act_cat(x[0], x[1], self.weight.data, self.bias.data, self.num_groups, self.eps, act)
         coef = ops.groupnorm_coef(x, self.weight.data, self.bias.data, self.num_groups, self.eps)
         return ops.affine_act(x, coef, act)
 

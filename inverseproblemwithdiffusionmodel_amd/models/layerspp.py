@@ -51,6 +51,22 @@ def _skip(x, h, rescale):
     return ops.axpby(x, h, INV_SQRT2, INV_SQRT2) if rescale else ops.add(x, h)
 
 
+class _TembBias:
+    """`h = Conv_0(.) ; h += Dense_0(act(temb))[:, :, None, None]` (reference models/layerspp.py:190-192, 252-254) as ONE bias row
+    per image in the convolution's epilogue: rows = Dense_0(act(temb)) with the convolution's own bias added into the
+    Dense bias (cached; refreshed when either parameter changes)"""
+
+    def __init__(self):
+        self._tag, self._sum = None, None
+
+    def rows(self, dense, conv, temb, code):
+        b_d, b_c = dense.bias.data, conv.bias.data
+        tag = (b_d._version, b_d.data_ptr(), b_c._version, b_c.data_ptr())
+        if tag != self._tag:
+            self._sum, self._tag = (b_d + b_c).contiguous(), tag
+        return ops.linear(temb, dense.weight.data, self._sum, code)
+
+
 class AttnBlockpp(nn.Module):
     """Channel-wise self-attention block. Modified from DDPM."""
 
@@ -138,17 +154,25 @@ class ResnetBlockDDPMpp(nn.Module):
             else:
                 self.NIN_0 = NIN(in_ch, out_ch)
         self.skip_rescale, self.act, self.out_ch, self.conv_shortcut = skip_rescale, act, out_ch, conv_shortcut
+        self._temb_bias = _TembBias()
 
     def forward(self, x, temb=None):
         code = self.act.code
-        h = self.Conv_0(self.GroupNorm_0(x, code))
-        if temb is not None:
-            t = self.Dense_0(temb, act_in=code)
-            shift = torch.stack([torch.zeros_like(t), torch.ones_like(t), t], dim=-1).contiguous()
-            h = ops.affine_act(h, shift, ops.ACT_NONE, out=h)
-        h = self.Conv_1(self.GroupNorm_1(h, code))
+        fold = self.Conv_0.epilogue_folds()
+        if temb is not None and fold:
+            h = self.Conv_0(self.GroupNorm_0(x, code), bounded=True, bias_rows=self._temb_bias.rows(self.Dense_0, self.Conv_0, temb, code))
+        else:
+            h = self.Conv_0(self.GroupNorm_0(x, code), bounded=True)
+            if temb is not None:
+                t = self.Dense_0(temb, act_in=code)
+                shift = torch.stack([torch.zeros_like(t), torch.ones_like(t), t], dim=-1).contiguous()
+                h = ops.affine_act(h, shift, ops.ACT_NONE, out=h)
         if x.shape[1] != self.out_ch:
             x = self.Conv_2(x) if self.conv_shortcut else self.NIN_0(x)
+        if fold:                                                   # (x + Conv_1(.)) [/ sqrt 2] in Conv_1's epilogue
+            return self.Conv_1(self.GroupNorm_1(h, code), residual=x, bounded=True,
+                               out_scale=INV_SQRT2 if self.skip_rescale else 1.0)
+        h = self.Conv_1(self.GroupNorm_1(h, code), bounded=True)
         return _skip(x, h, self.skip_rescale)
 
 
@@ -167,26 +191,54 @@ class ResnetBlockBigGANpp(nn.Module):
         if in_ch != out_ch or up or down:
             self.Conv_2 = conv1x1(in_ch, out_ch)
         self.skip_rescale, self.act, self.in_ch, self.out_ch = skip_rescale, act, in_ch, out_ch
+        self._temb_bias = _TembBias()
 
-    def forward(self, x, temb=None):
+    def forward(self, x, temb=None, x2=None):
+        """x2: the block's input is torch.cat([x, x2], dim=1) (the up path's skip connections, reference models/ncsnpp.py:351)
+        -- evaluated without the concatenation: GroupNorm_0 normalises the two tensors into one buffer, the 1x1 shortcut
+        Conv_2 runs as two chained parts"""
         code = self.act.code
-        h = self.GroupNorm_0(x, code)
+        parts = None
+        if x2 is not None:
+            if self.Conv_0.epilogue_folds() and self.Conv_2.kernel_size == 1:
+                parts = [x, x2]
+                h = self.GroupNorm_0((x, x2), code)
+            else:
+                x = torch.cat([x, x2], dim=1)
+        if parts is None:
+            h = self.GroupNorm_0(x, code)
         if self.up:
             f = (lambda t: up_or_down_sampling.upsample_2d(t, self.fir_kernel, factor=2)) if self.fir else \
                 (lambda t: up_or_down_sampling.naive_upsample_2d(t, factor=2))
-            h, x = f(h), f(x)
+            h = f(h)
+            if parts is None:
+                x = f(x)
+            else:
+                parts = [f(t) for t in parts]
         elif self.down:
             f = (lambda t: up_or_down_sampling.downsample_2d(t, self.fir_kernel, factor=2)) if self.fir else \
                 (lambda t: up_or_down_sampling.naive_downsample_2d(t, factor=2))
-            h, x = f(h), f(x)
-        h = self.Conv_0(h)
-        if temb is not None:
-            # h += Dense_0(act(temb))[:, :, None, None]: a per-(image, channel) shift, applied as affine coefficients
-            t = self.Dense_0(temb, act_in=code)
-            shift = torch.stack([torch.zeros_like(t), torch.ones_like(t), t], dim=-1).contiguous()
-            h = ops.affine_act(h, shift, ops.ACT_NONE, out=h)
+            h = f(h)
+            if parts is None:
+                x = f(x)
+            else:
+                parts = [f(t) for t in parts]
+        fold = self.Conv_0.epilogue_folds()
+        if temb is not None and fold:
+            # h += Dense_0(act(temb))[:, :, None, None]: one bias row per image in Conv_0's epilogue
+            h = self.Conv_0(h, bounded=True, bias_rows=self._temb_bias.rows(self.Dense_0, self.Conv_0, temb, code))
+        else:
+            h = self.Conv_0(h, bounded=True)                     # act(GroupNorm(x)), FIR-resampled: bounded
+            if temb is not None:
+                t = self.Dense_0(temb, act_in=code)
+                shift = torch.stack([torch.zeros_like(t), torch.ones_like(t), t], dim=-1).contiguous()
+                h = ops.affine_act(h, shift, ops.ACT_NONE, out=h)
         h = self.GroupNorm_1(h, code)
-        h = self.Conv_1(h)
         if self.in_ch != self.out_ch or self.up or self.down:
-            x = self.Conv_2(x)
+            x = self.Conv_2.forward_parts(parts) if parts is not None else self.Conv_2(x)
+        elif parts is not None:
+            x = torch.cat(parts, dim=1)
+        if fold:                                                   # (x + Conv_1(h)) [/ sqrt 2] in Conv_1's epilogue
+            return self.Conv_1(h, residual=x, bounded=True, out_scale=INV_SQRT2 if self.skip_rescale else 1.0)
+        h = self.Conv_1(h, bounded=True)
         return _skip(x, h, self.skip_rescale)

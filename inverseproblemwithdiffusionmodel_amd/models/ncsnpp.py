@@ -191,7 +191,10 @@ class NCSNpp(nn.Module):
         pyramid = None
         for i_level in reversed(range(self.num_resolutions)):
             for i_block in range(self.num_res_blocks + 1):
-                h = modules[m_idx](torch.cat([h, hs.pop()], dim=1), temb)
+                if self.resblock_type == 'biggan':
+                    h = modules[m_idx](h, temb, x2=hs.pop())          # cat([h, skip]) evaluated without the concatenation
+                else:
+                    h = modules[m_idx](torch.cat([h, hs.pop()], dim=1), temb)
                 m_idx += 1
             if h.shape[-1] in self.attn_resolutions:
                 h = modules[m_idx](h)
@@ -200,9 +203,9 @@ class NCSNpp(nn.Module):
                 pyramid_h = modules[m_idx](h, code)                   # act(GroupNorm(h))
                 m_idx += 1
                 if pyramid is None:
-                    pyramid = modules[m_idx](pyramid_h)
+                    pyramid = modules[m_idx](pyramid_h, bounded=True)
                 else:
-                    pyramid = modules[m_idx](pyramid_h, residual=self.pyramid_upsample(pyramid))
+                    pyramid = modules[m_idx](pyramid_h, residual=self.pyramid_upsample(pyramid), bounded=True)
                 m_idx += 1
             if i_level != 0:
                 h = modules[m_idx](h) if self.resblock_type == 'ddpm' else modules[m_idx](h, temb)
@@ -213,7 +216,7 @@ class NCSNpp(nn.Module):
         else:
             h = modules[m_idx](h, code)
             m_idx += 1
-            h = modules[m_idx](h)
+            h = modules[m_idx](h, bounded=True)
             m_idx += 1
         assert m_idx == len(modules)
         if self.config.model.scale_by_sigma:

@@ -74,7 +74,8 @@ def conv_downsample_2d(x, w, k=None, factor=2, gain=1, packed=None, bias=None):
     fir = _fir(k, gain, x.device)
     p = (fir.shape[0] - factor) + (convW - 1)
     x = upfirdn2d(x, fir, pad=((p + 1) // 2, p // 2))
-    return ops.conv2d_stride2_valid(x, ops.conv_weight(w, ops.impl_unbounded()) if packed is None else packed, bias, convW)
+    return ops.conv2d_stride2_valid(x, ops.conv_weight(w, ops.impl_unbounded()) if packed is None else packed, bias, convW,
+                                    in_amax=ops.unbounded_amax())
 
 
 class Conv2d(ops.PackedWeightMixin, nn.Module):
@@ -101,4 +102,4 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
         if self.down:                   # the bias rides in the convolution epilogue (= x + bias.reshape(1, -1, 1, 1) afterwards)
             return conv_downsample_2d(x, self.weight, k=self.resample_kernel, packed=packed,
                                       bias=self.bias.data if self.use_bias else None)
-        return ops.conv2d(x, packed, self.bias.data if self.use_bias else None)
+        return ops.conv2d(x, packed, self.bias.data if self.use_bias else None, in_amax=ops.unbounded_amax())

@@ -3,6 +3,7 @@ PyTorch-ROCm (plumbing), all arithmetic happens in the hand-written HIP kernels 
 
 Every function requires GPU tensors and raises otherwise -- there is no CPU path.
 """
+import ctypes
 import os
 
 import torch
@@ -290,11 +291,11 @@ def subsample2(x, offset=(0, 0), size=None):
     return out
 
 
-def conv2d_stride2_valid(x, wt, bias=None, ksize=3):
+def conv2d_stride2_valid(x, wt, bias=None, ksize=3, in_amax=None):
     """F.conv2d(x, w, stride=2, padding=0) for an odd kernel on the stride-1 MFMA kernel: the 'same' convolution sampled at
     (k//2, k//2) + 2(i, j).  wt: the packed weight of the same layer (conv_weight)."""
     H, W = x.shape[-2:]
-    full = conv2d(x, wt, bias)
+    full = conv2d(x, wt, bias, in_amax=in_amax)
     o = ksize // 2
     return subsample2(full, (o, o), ((H - ksize) // 2 + 1, (W - ksize) // 2 + 1))
 
@@ -530,6 +531,26 @@ def groupnorm_coef(x, weight, bias, groups, eps=1e-6):
     return coef
 
 
+def groupnorm_act_cat(x1, x2, weight, bias, groups, eps=1e-6, act=ACT_NONE):
+    """act(GroupNorm(torch.cat([x1, x2], dim=1))) without materialising the concatenation of the RAW tensors; falls back to
+    the concatenation where the two-source kernels do not apply"""
+    x1, x2 = _gpu(x1, torch.float32, "x1"), _gpu(x2, torch.float32, "x2")
+    B, C1, H, W = x1.shape
+    C2 = x2.shape[1]
+    if tuple(x2.shape) != (B, C2, H, W):
+        raise ValueError(f"groupnorm_act_cat: {tuple(x1.shape)} vs {tuple(x2.shape)}")
+    coef = torch.empty((B, C1 + C2, 3), dtype=torch.float32, device=x1.device)
+    out = torch.empty((B, C1 + C2, H, W), dtype=torch.float32, device=x1.device)
+    try:
+        call("ipdm_groupnorm_coef_cat_f32", _ptr(x1), C1, _ptr(x2), C2, _ptr(weight), _ptr(bias), _ptr(coef), B, H * W, groups,
+             float(eps), _stream())
+        call("ipdm_affine_act_cat_f32", _ptr(x1), C1, _ptr(x2), C2, _ptr(coef), _ptr(out), B, H * W, act, _stream())
+        return out
+    except _lib.IpdmUnsupported:
+        x = torch.cat([x1, x2], dim=1)
+        return affine_act(x, groupnorm_coef(x, weight, bias, groups, eps), act)
+
+
 def linear(x, weight, bias=None, act_in=ACT_NONE):
     x = _gpu(x, torch.float32, "x")
     B, In = x.shape
@@ -672,7 +693,7 @@ def temporal_taps(x, mode):
 
 
 def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, pool2=False, out=None,
-           act_out=ACT_NONE, raw=True):
+           act_out=ACT_NONE, raw=True, in_amax=None, out_scale=1.0):
     """x [B,Cin,H,W]; wt packed [k*k,Cin,Cout].  Input side: optional InstanceNorm++ coefficients / activation.
     Output side: bias, residual add; act_out != NONE additionally returns the activated copy act_out(result)
     (raw=False: ONLY the activated copy is produced).  Returns out, or (out, out_act) when act_out is set
@@ -680,7 +701,10 @@ def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1,
     if isinstance(wt, PackedBx3):
         if pool2:
             raise _lib.IpdmUnsupported("conv2d: pool2 epilogue is not fused")
-        return conv_bx3(x, wt, bias, coef, act, residual, dilation, out=out, act_out=act_out, raw=raw)
+        return conv_bx3(x, wt, bias, coef, act, residual, dilation, out=out, act_out=act_out, raw=raw, in_amax=in_amax,
+                        out_scale=out_scale)
+    if out_scale != 1.0 or (bias is not None and bias.dim() == 2):
+        raise _lib.IpdmUnsupported("conv2d: per-image bias / out_scale exist on the split-operand kernels only")
     x = _gpu(x, torch.float32, "x")
     B, Cin, H, W = x.shape
     kk, Cin_w, Cout = wt.shape
@@ -759,14 +783,21 @@ def split_impl():
 
 def impl_unbounded():
     """kernel family for networks whose convolution inputs are NOT bounded by a per-plane normalisation (NCSN++: GroupNorm'ed
-    blocks but raw progressive / skip streams -- 1.7e5 in the full-size golden forward g22): the f16x2 family's range
-    contract (|x| < 65504) does not hold there, so "hx2" is replaced by "bx3" (IPDM_CONV_IMPL_UNBOUNDED overrides)."""
+    blocks but raw progressive / skip streams -- 1.7e5 in the full-size golden forward g22): the f16x2 family's STATIC range
+    contract (|x| < 65504) does not hold there; these networks run it with the DYNAMIC range instead (`unbounded_amax()`:
+    one ipdm_absmax_f32 pass per convolution input, every image scaled into fp16's range by an exact power of two).
+    IPDM_CONV_IMPL_UNBOUNDED overrides the family (e.g. bx3: three bf16 pieces, the whole fp32 exponent range, no extra pass)."""
     env = os.environ.get("IPDM_CONV_IMPL_UNBOUNDED")
     if env:
         if env not in SPLIT_IMPLS + ("f32",):
             raise ValueError(f"IPDM_CONV_IMPL_UNBOUNDED={env!r}")
         return env
-    return "bx3" if CONV_IMPL == "hx2" else CONV_IMPL
+    return CONV_IMPL
+
+
+def unbounded_amax():
+    """the `in_amax` argument those networks pass to their convolutions: True (measure the input) on the f16x2 family"""
+    return True if impl_unbounded() == "hx2" else None
 
 
 class PackedWeightCache:
@@ -816,6 +847,39 @@ class PackedBx3:
         self.blob, self.Cout, self.Cin, self.kk, self.fmt = blob, Cout, Cin, kk, fmt
 
 
+def absmax_per_image(x):
+    """per-image max |x| (float32 [B]) of an activation tensor: the `in_amax` of the f16x2 convolutions' dynamic range"""
+    x = _gpu(x, torch.float32, "x")
+    B = x.shape[0]
+    out = torch.empty(B, dtype=torch.float32, device=x.device)
+    call("ipdm_absmax_f32", _ptr(x), _ptr(out), B, x.numel() // max(B, 1), _stream())
+    return out
+
+
+def _conv_ext(fmt, in_amax, x, fused_input, bias_per_image=False, out_scale=1.0, Cout=0):
+    """-> the `ext` argument of the split-operand entry points (NULL when every extra is at its default).
+    in_amax (hx2 blobs only): None -> static range contract; True -> measure the input here; a tensor -> as given (a fused input
+    normalisation / activation makes the raw maximum meaningless: ignored).  bias_per_image: bias is [B, Cout].  out_scale:
+    result = (conv + bias + residual) * out_scale."""
+    amax_ptr = None
+    if fmt == "hx2" and in_amax is not None and not fused_input:
+        if in_amax is True:
+            in_amax = absmax_per_image(x)
+        if in_amax.numel() != x.shape[0] or in_amax.dtype != torch.float32 or not in_amax.is_cuda:
+            raise ValueError("in_amax: expected a float32 GPU tensor with one entry per image")
+        amax_ptr = in_amax.data_ptr()
+        _KEEP.append(in_amax)                    # (the kernel reads it asynchronously: keep the tensor alive until the call returns)
+    if amax_ptr is None and not bias_per_image and out_scale == 1.0:
+        return P(0)
+    ext = _lib.ConvExt(amax_ptr, int(Cout) if bias_per_image else 0, float(out_scale))
+    _KEEP.append(ext)
+    del _KEEP[:-8]
+    return ctypes.byref(ext)
+
+
+_KEEP = []                                       # last few ext structs / amax tensors (host structs are read during the call)
+
+
 def conv_hx2_weight(w):
     return conv_bx3_weight(w, fmt="hx2")
 
@@ -841,9 +905,16 @@ def conv_bx3_weight(w, fmt="bx3"):
     return PackedBx3(blob, Cout, Cin, kk, fmt)
 
 
-def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, out=None, act_out=ACT_NONE, raw=True):
-    """2-D ([B,Cin,H,W]) or 3-D ([B,Cin,D,H,W]) convolution, same options / return convention as conv2d / conv3d"""
+def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, out=None, act_out=ACT_NONE, raw=True,
+             in_amax=None, out_scale=1.0):
+    """2-D ([B,Cin,H,W]) or 3-D ([B,Cin,D,H,W]) convolution, same options / return convention as conv2d / conv3d.
+    in_amax (hx2 blobs only): None = static range contract |x| < 65504, True = measure the input (ipdm_absmax_f32) and scale every
+    image into fp16's range, or the per-image maxima themselves"""
     x = _gpu(x, torch.float32, "x")
+    bias_per_image = bias is not None and bias.dim() == 2
+    if bias_per_image and tuple(bias.shape) != (x.shape[0], wq.Cout):
+        raise ValueError(f"conv_bx3: per-image bias {tuple(bias.shape)} != {(x.shape[0], wq.Cout)}")
+    ext = _conv_ext(wq.fmt, in_amax, x, coef is not None or act != ACT_NONE, bias_per_image, out_scale, wq.Cout)
     if wq.Cin != x.shape[1]:
         raise ValueError(f"conv_bx3: weight Cin {wq.Cin} != input Cin {x.shape[1]}")
     vol = x.dim() == 5
@@ -871,13 +942,13 @@ def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=
     if ksplit > 1:        # too few tiles to fill the chip: deal the K loop to several workgroups per tile
         work = torch.empty((ksplit,) + shape, dtype=torch.float32, device=x.device)
         call(f"ipdm_conv_{wq.fmt}_splitk_f32", _ptr(x), _ptr(wq.blob), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
-             _ptr(out_act), act_out, B, Cin, wq.Cout, D, H, W, k, dilation, int(vol), ksplit, _ptr(work), _stream())
+             _ptr(out_act), act_out, B, Cin, wq.Cout, D, H, W, k, dilation, int(vol), ksplit, _ptr(work), ext, _stream())
     elif vol:
         call(f"ipdm_conv3d_{wq.fmt}_f32", _ptr(x), _ptr(wq.blob), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
-             _ptr(out_act), act_out, B, Cin, wq.Cout, D, H, W, k, dilation, _stream())
+             _ptr(out_act), act_out, B, Cin, wq.Cout, D, H, W, k, dilation, ext, _stream())
     else:
         call(f"ipdm_conv2d_{wq.fmt}_f32", _ptr(x), _ptr(wq.blob), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out),
-             _ptr(out_act), act_out, B, Cin, wq.Cout, H, W, k, dilation, _stream())
+             _ptr(out_act), act_out, B, Cin, wq.Cout, H, W, k, dilation, ext, _stream())
     if CONV_TRACE is not None:
         e1.record()
         CONV_TRACE.append(dict(B=B * D, Cin=Cin, Cout=wq.Cout, H=H, W=W, k=k, dil=dilation, bx3=True, fmt=wq.fmt, res=residual is not None,
@@ -912,7 +983,8 @@ def conv_wino_bx3_supported(Cin, Cout, H, W, dilation=1):
     return bool(_lib.lib.ipdm_conv2d_wino_bx3_supported(Cin, Cout, H, W, dilation))
 
 
-def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dilation=1, pool2=False, want_stats=False):
+def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dilation=1, pool2=False, want_stats=False,
+                    in_amax=None, out_scale=1.0):
     """3x3 convolution through the split-bf16 Winograd kernel (same output options as conv2d).
     pool2: the ConvMeanPool form -- outputs (and the residual) are [B, Cout, H/2, W/2] 2x2 means of the convolution;
     raises IpdmUnsupported where the pooled epilogue is not built (small / odd images).
@@ -920,6 +992,18 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
     [B, Cout, P, 3] are hung on the raw result as `_ipdm_partials` (instnorm_plus_coef picks them up)."""
     x = _gpu(x, torch.float32, "x")
     B, Cin, H, W = x.shape
+    amax_t = None
+    if U.fmt == "hx2" and in_amax is not None:
+        amax_t = absmax_per_image(x) if in_amax is True else in_amax
+    bias_per_image = bias is not None and bias.dim() == 2
+    if bias_per_image and tuple(bias.shape) != (B, U.Cout):
+        raise ValueError(f"conv2d_wino_bx3: per-image bias {tuple(bias.shape)} != {(B, U.Cout)}")
+
+    def ext_of(b0, b1):
+        return _conv_ext(U.fmt, None if amax_t is None else amax_t[b0:b1], x[b0:b1], False, bias_per_image, out_scale, U.Cout)
+
+    def bias_of(b0, b1):
+        return bias[b0:b1] if bias_per_image else bias
     if U.kk != 16 or U.Cin != Cin:
         raise ValueError("conv2d_wino_bx3: weight blob does not match the input")
     Cout = U.Cout
@@ -938,10 +1022,10 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
         for b0 in range(0, B, nb):
             b1 = min(B, b0 + nb)
             work = torch.empty((ksplit, b1 - b0, Cout, H, W), dtype=torch.float32, device=x.device)
-            call(f"ipdm_conv2d_wino_{U.fmt}_splitk_f32", _ptr(x[b0:b1]), _ptr(U.blob), _ptr(bias),
+            call(f"ipdm_conv2d_wino_{U.fmt}_splitk_f32", _ptr(x[b0:b1]), _ptr(U.blob), _ptr(bias_of(b0, b1)),
                  _ptr(None if residual is None else residual[b0:b1]), _ptr(None if out is None else out[b0:b1]),
                  _ptr(None if out_act is None else out_act[b0:b1]), act_out, b1 - b0, Cin, Cout, H, W, dilation, ksplit,
-                 _ptr(work), _stream())
+                 _ptr(work), ext_of(b0, b1), _stream())
         if CONV_TRACE is not None:
             e1.record()
             CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, fmt=U.fmt, res=residual is not None,
@@ -954,17 +1038,18 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
             part = torch.empty((B, Cout, P, 3), dtype=torch.float32, device=x.device)
     for b0 in range(0, B, nb):           # one launch unless the batch outgrows the kernel's 32-bit buffer offsets
         b1 = min(B, b0 + nb)
-        args = (_ptr(x[b0:b1]), _ptr(U.blob), _ptr(bias),
+        args = (_ptr(x[b0:b1]), _ptr(U.blob), _ptr(bias_of(b0, b1)),
                 _ptr(None if residual is None else residual[b0:b1]), _ptr(None if out is None else out[b0:b1]),
                 _ptr(None if out_act is None else out_act[b0:b1]), act_out, b1 - b0, Cin, Cout, H, W, dilation,
                 int(bool(pool2)))
+        am = (ext_of(b0, b1),)
         if part is not None:
             try:
-                call(f"ipdm_conv2d_wino_{U.fmt}_stats_f32", *args, _ptr(part[b0:b1]), _stream())
+                call(f"ipdm_conv2d_wino_{U.fmt}_stats_f32", *args, _ptr(part[b0:b1]), *am, _stream())
                 continue
             except _lib.IpdmUnsupported:         # e.g. IPDM_WBX3_DMA4=0: no statistics epilogue on that kernel form
                 part = None
-        call(f"ipdm_conv2d_wino_{U.fmt}_f32", *args, _stream())
+        call(f"ipdm_conv2d_wino_{U.fmt}_f32", *args, *am, _stream())
     if part is not None:
         out._ipdm_partials = (part, (out._version, out.data_ptr()))
     if CONV_TRACE is not None:

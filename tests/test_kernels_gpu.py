@@ -997,6 +997,43 @@ def test_conv_hx2_exactness_and_layout(ops):
     assert torch.isfinite(got3[0]).all()
 
 
+@pytest.mark.parametrize("scale", [1.0e5, 3.0e7, 1.0e-6, 1.0])
+def test_conv_hx2_dynamic_range(ops, scale):
+    """f16x2 with `in_amax`: every image is scaled into fp16's range by an exact power of two (ipdm_absmax_f32 ->
+    hx_dynamic_scale) and unscaled in the epilogue, so inputs far beyond 65504 -- or far below fp16's normal range -- give the
+    same float64-referenced accuracy as O(1) inputs; images of one batch may differ by many orders of magnitude.  Direct,
+    Winograd (wide, small / dilated, split-K) and 3-D forms."""
+    gen = torch.Generator().manual_seed(23)
+    for (B, Cin, Cout, H, W, dil, wino) in [(3, 64, 64, 32, 32, 1, True), (2, 32, 64, 16, 16, 2, True), (3, 256, 256, 16, 16, 1, True),
+                                            (2, 32, 48, 20, 24, 1, False), (2, 128, 64, 40, 36, 1, True)]:
+        x = torch.randn(B, Cin, H, W, generator=gen)
+        x[0] *= scale
+        if B > 2:
+            x[2] *= 1.0e-3                                   # a third image many orders below the first
+        w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (9 * Cin) ** 0.5
+        b = torch.randn(Cout, generator=gen)
+        want = F.conv2d(x.double(), w.double(), None, padding=dil, dilation=dil)
+        if wino:
+            assert ops.conv_wino_bx3_supported(Cin, Cout, H, W, dil)
+            got = ops.conv2d_wino_bx3(x.cuda(), ops.conv_wino_hx2_weight(w.cuda()), None, dilation=dil, in_amax=True)
+        else:
+            got = ops.conv_bx3(x.cuda(), ops.conv_hx2_weight(w.cuda()), None, dilation=dil, in_amax=True)
+        got = got.cpu().double()
+        assert torch.isfinite(got).all()
+        for i in range(B):                                   # per image: error relative to THAT image's output range
+            assert (got[i] - want[i]).abs().max() <= 1e-5 * want[i].abs().max(), (scale, i, Cin, H)
+    am = ops.absmax_per_image(x.cuda()).cpu()
+    assert torch.equal(am, x.abs().amax(dim=(1, 2, 3)))
+    x3 = torch.randn(2, 16, 6, 8, 24, generator=gen) * scale
+    w3 = torch.randn(32, 16, 3, 3, 3, generator=gen) / (27 * 16) ** 0.5
+    want3 = F.conv3d(x3.double(), w3.double(), padding=1)
+    got3 = ops.conv_bx3(x3.cuda(), ops.conv_hx2_weight(w3.cuda()), in_amax=True).cpu().double()
+    assert (got3 - want3).abs().max() <= 1e-5 * want3.abs().max()
+    if scale > 65504:                                        # ... and without in_amax the static contract answers with inf / NaN
+        bad = ops.conv_bx3(x3.cuda(), ops.conv_hx2_weight(w3.cuda())).cpu()
+        assert not torch.isfinite(bad).all()
+
+
 @pytest.mark.parametrize("fmt", ["bx3", "hx2"])
 def test_conv_bx3_activated_second_output(ops, fmt):
     gen = torch.Generator().manual_seed(14)
