@@ -237,13 +237,17 @@ int ipdm_trilinear_f32(const float* x, float* out, int planes, int in_d, int in_
  * ---------------------------------------------------------------------------------------------- */
 /* GroupNorm as per-(b,c) coefficients (mu, weight*rstd, bias) for ipdm_affine_act_f32 / the conv prologue */
 int ipdm_groupnorm_coef_f32(const float* x, const float* weight, const float* bias, float* coef,
-                            int B, int C, int HW, int G, float eps, void* stream);
+                            int B, int C, int HW, int G, float eps,
+                            float* plane_amax /* may be NULL; [B][C]: max |x| per plane from the same pass (single-read
+                                                 plane kernels only, IPDM_EUNSUPPORTED otherwise) */,
+                            void* stream);
 /* GroupNorm (+ activation) of torch.cat([x1, x2], dim=1) WITHOUT the concatenation (the up path of NCSN++ feeds every block
  * `torch.cat([h, hs.pop()], dim=1)`, models/ncsnpp.py:351): coefficients [B][C1+C2][3] from the two tensors' planes, then one
  * pass that writes the normalised, activated, concatenated tensor.  IPDM_EUNSUPPORTED outside the single-read plane kernels
  * (HW % 4 != 0, HW > 65536, more than 65535 planes): concatenate and use the one-tensor calls. */
 int ipdm_groupnorm_coef_cat_f32(const float* x1, int C1, const float* x2, int C2, const float* weight, const float* bias,
-                                float* coef, int B, int HW, int G, float eps, void* stream);
+                                float* coef, int B, int HW, int G, float eps, float* plane_amax /* may be NULL; [B][C1+C2] */,
+                                void* stream);
 int ipdm_affine_act_cat_f32(const float* x1, int C1, const float* x2, int C2, const float* coef, float* y, int B, int HW,
                             int act, void* stream);
 /* y[b][o] = bias[o] + sum_i act(x[b][i]) * W[o][i]   (torch.nn.Linear weight layout [Out][In]) */

@@ -55,9 +55,11 @@ __global__ __launch_bounds__(256) void groupnorm_coef_kernel(const float* __rest
 // against (B x G) workgroups sweeping (C/G)*HW elements twice in groupnorm_coef_kernel (kept for larger planes).
 // (c_src, c_tot, c_off): the planes of `x` are channels c_off .. c_off + c_src - 1 of a (virtual) tensor of c_tot channels whose
 // coefficients `coef` holds -- GroupNorm over torch.cat([x1, x2], dim=1) without the concatenation; (C, C, 0) otherwise
+// plane_amax (may be NULL): max |x| of the plane, same slot -- the f16x2 convolutions' dynamic range for free where the tensor is
+// normalised anyway (the plane is in registers)
 template <int T>
 __global__ __launch_bounds__(T) void gn_plane_kernel(const float* __restrict__ x, float* __restrict__ coef, int HW, int c_src,
-                                                     int c_tot, int c_off) {
+                                                     int c_tot, int c_off, float* __restrict__ plane_amax) {
   __shared__ double red[T / 64];
   const float* p = x + (size_t)blockIdx.x * HW;
   const size_t slot = (size_t)(blockIdx.x / c_src) * c_tot + c_off + blockIdx.x % c_src;
@@ -81,12 +83,26 @@ __global__ __launch_bounds__(T) void gn_plane_kernel(const float* __restrict__ x
   for (int w = 0; w < T / 64; ++w) tot += red[w];
   const float mean = (float)(tot / (double)HW);
   __syncthreads();
-  float q = 0.f;
+  float q = 0.f, am = 0.f;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     if (tid + k * T < n4) {
       const float a = keep[k].x - mean, b = keep[k].y - mean, c = keep[k].z - mean, d = keep[k].w - mean;
       q += (a * a + b * b) + (c * c + d * d);
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(keep[k].x), fabsf(keep[k].y))), fmaxf(fabsf(keep[k].z), fabsf(keep[k].w)));
+    }
+  }
+  if (plane_amax) {                                            // (uniform branch)
+    __shared__ float redm[T / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    if (lane == 0) redm[wave] = am;
+    __syncthreads();
+    if (tid == 0) {
+      float m = 0.f;
+#pragma unroll
+      for (int w = 0; w < T / 64; ++w) m = fmaxf(m, redm[w]);
+      plane_amax[slot] = m;
     }
   }
   double dq = ipdm_wave_sum((double)q);
@@ -258,18 +274,19 @@ extern "C" int ipdm_adam_ascent_f32(float* x, const float* g, float* m, float* v
 }
 
 extern "C" int ipdm_groupnorm_coef_f32(const float* x, const float* weight, const float* bias, float* coef, int B, int C,
-                                       int HW, int G, float eps, void* stream) {
+                                       int HW, int G, float eps, float* plane_amax, void* stream) {
   IPDM_REQUIRE(B >= 0 && C > 0 && HW > 0 && G > 0 && C % G == 0);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && coef);
   if (HW % 4 == 0 && HW <= 65536 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     if (HW <= 16384)
-      hipLaunchKernelGGL(gn_plane_kernel<256>, dim3(B * C), dim3(256), 0, ipdm_stream(stream), x, coef, HW, C, C, 0);
+      hipLaunchKernelGGL(gn_plane_kernel<256>, dim3(B * C), dim3(256), 0, ipdm_stream(stream), x, coef, HW, C, C, 0, plane_amax);
     else
-      hipLaunchKernelGGL(gn_plane_kernel<1024>, dim3(B * C), dim3(1024), 0, ipdm_stream(stream), x, coef, HW, C, C, 0);
+      hipLaunchKernelGGL(gn_plane_kernel<1024>, dim3(B * C), dim3(1024), 0, ipdm_stream(stream), x, coef, HW, C, C, 0, plane_amax);
     hipLaunchKernelGGL(gn_combine_kernel, dim3(B * G), dim3(64), 0, ipdm_stream(stream), weight, bias, coef, C, HW, G, eps);
     return ipdm_launch_status();
   }
+  if (plane_amax) return IPDM_EUNSUPPORTED;                   // the two-sweep fallback does not carry the maxima
   hipLaunchKernelGGL(groupnorm_coef_kernel, dim3(B * G), dim3(256), 0, ipdm_stream(stream), x, weight, bias, coef, C, HW,
                      G, eps);
   return ipdm_launch_status();
@@ -278,7 +295,8 @@ extern "C" int ipdm_groupnorm_coef_f32(const float* x, const float* weight, cons
 // GroupNorm coefficients of torch.cat([x1, x2], dim=1) without the concatenation (single-read plane kernels only: planes of
 // whole float4s up to 256 x 256; IPDM_EUNSUPPORTED otherwise -- the caller concatenates and uses ipdm_groupnorm_coef_f32)
 extern "C" int ipdm_groupnorm_coef_cat_f32(const float* x1, int C1, const float* x2, int C2, const float* weight,
-                                           const float* bias, float* coef, int B, int HW, int G, float eps, void* stream) {
+                                           const float* bias, float* coef, int B, int HW, int G, float eps, float* plane_amax,
+                                           void* stream) {
   const int C = C1 + C2;
   IPDM_REQUIRE(B >= 0 && C1 > 0 && C2 > 0 && HW > 0 && G > 0 && C % G == 0);
   if (B == 0) return IPDM_OK;
@@ -287,11 +305,11 @@ extern "C" int ipdm_groupnorm_coef_cat_f32(const float* x1, int C1, const float*
     return IPDM_EUNSUPPORTED;
   hipStream_t s = ipdm_stream(stream);
   if (HW <= 16384) {
-    hipLaunchKernelGGL(gn_plane_kernel<256>, dim3(B * C1), dim3(256), 0, s, x1, coef, HW, C1, C, 0);
-    hipLaunchKernelGGL(gn_plane_kernel<256>, dim3(B * C2), dim3(256), 0, s, x2, coef, HW, C2, C, C1);
+    hipLaunchKernelGGL(gn_plane_kernel<256>, dim3(B * C1), dim3(256), 0, s, x1, coef, HW, C1, C, 0, plane_amax);
+    hipLaunchKernelGGL(gn_plane_kernel<256>, dim3(B * C2), dim3(256), 0, s, x2, coef, HW, C2, C, C1, plane_amax);
   } else {
-    hipLaunchKernelGGL(gn_plane_kernel<1024>, dim3(B * C1), dim3(1024), 0, s, x1, coef, HW, C1, C, 0);
-    hipLaunchKernelGGL(gn_plane_kernel<1024>, dim3(B * C2), dim3(1024), 0, s, x2, coef, HW, C2, C, C1);
+    hipLaunchKernelGGL(gn_plane_kernel<1024>, dim3(B * C1), dim3(1024), 0, s, x1, coef, HW, C1, C, 0, plane_amax);
+    hipLaunchKernelGGL(gn_plane_kernel<1024>, dim3(B * C2), dim3(1024), 0, s, x2, coef, HW, C2, C, C1, plane_amax);
   }
   hipLaunchKernelGGL(gn_combine_kernel, dim3(B * G), dim3(64), 0, s, weight, bias, coef, C, HW, G, eps);
   return ipdm_launch_status();

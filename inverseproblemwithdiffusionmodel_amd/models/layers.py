@@ -56,13 +56,15 @@ class Conv(ops.PackedWeightMixin, nn.Module):
         impl = ops.impl_unbounded()
         return self._cache.get(self.weight, "wino_" + impl, lambda w: ops.conv_wino_split_weight(w, impl))
 
-    def forward(self, x, residual=None, bounded=False, bias_rows=None, out_scale=1.0):
+    def forward(self, x, residual=None, bounded=False, bias_rows=None, out_scale=1.0, in_amax=None):
         """bounded: x is act(GroupNorm(.)) (possibly FIR-resampled) -- |x| <= |gamma| sqrt(group size) + |beta|, inside the
         f16x2 family's static range; otherwise (raw skip / pyramid / input streams) the convolution measures its input and
         runs with the dynamic range (ops.unbounded_amax).
         bias_rows [B, Cout]: replaces the bias by one row per image (the caller has added self.bias into it);
         out_scale: result = (conv + bias + residual) * out_scale -- both folded into the epilogue (split families only)."""
         amax = None if bounded else ops.unbounded_amax()
+        if amax is not None and in_amax is not None:
+            amax = in_amax                       # an upper bound of max |x| per image the caller already has
         bias = None if self.bias is None else self.bias.data
         if bias_rows is not None:
             bias = bias_rows
@@ -79,7 +81,7 @@ class Conv(ops.PackedWeightMixin, nn.Module):
         """True when per-image bias rows / out_scale can ride in this convolution's epilogue (split-operand kernels)"""
         return ops.impl_unbounded() in ops.SPLIT_IMPLS and not (self.kernel_size == 3 and min(self.in_planes, self.out_planes) <= 3)
 
-    def forward_parts(self, xs, residual=None, out_scale=1.0):
+    def forward_parts(self, xs, residual=None, out_scale=1.0, in_amax=None):
         """the convolution of torch.cat(xs, dim=1) WITHOUT the concatenation: sum_i conv(xs[i], weight[:, slice_i]), each part
         taking the previous sum as its residual (the bias rides with the first, out_scale with the last).  1x1 kernels."""
         assert self.kernel_size == 1 and sum(t.shape[1] for t in xs) == self.in_planes
@@ -91,7 +93,8 @@ class Conv(ops.PackedWeightMixin, nn.Module):
                                      lambda w, a=c0, b=c1: ops.conv_weight(w[:, a:b].contiguous(), impl))
             last = i == len(xs) - 1
             acc = ops.conv2d(t, packed, self.bias.data if (i == 0 and self.bias is not None) else None, residual=acc,
-                             in_amax=ops.unbounded_amax(), out_scale=out_scale if last else 1.0)
+                             in_amax=(in_amax if in_amax is not None and ops.unbounded_amax() else ops.unbounded_amax()),
+                             out_scale=out_scale if last else 1.0)
             c0 = c1
         return acc
 
@@ -141,9 +144,15 @@ class GroupNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(num_channels))
         self.bias = nn.Parameter(torch.zeros(num_channels))
 
-    def forward(self, x, act=ops.ACT_NONE):
+    def forward(self, x, act=ops.ACT_NONE, want_amax=False):
+        """want_amax: -> (y, per-image max |x| [B]): what a convolution of the RAW x needs for its dynamic range, from the
+        statistics pass that reads x anyway"""
         if isinstance(x, (tuple, list)):        # GroupNorm(+act) of torch.cat(x, dim=1) without the concatenation
-            return ops.groupnorm_act_cat(x[0], x[1], self.weight.data, self.bias.data, self.num_groups, self.eps, act)
+            return ops.groupnorm_act_cat(x[0], x[1], self.weight.data, self.bias.data, self.num_groups, self.eps, act,
+                                         want_amax=want_amax)
+        if want_amax:
+            coef, am = ops.groupnorm_coef(x, self.weight.data, self.bias.data, self.num_groups, self.eps, want_amax=True)
+            return ops.affine_act(x, coef, act), am
         coef = ops.groupnorm_coef(x, self.weight.data, self.bias.data, self.num_groups, self.eps)
         return ops.affine_act(x, coef, act)
 

@@ -199,14 +199,20 @@ class ResnetBlockBigGANpp(nn.Module):
         Conv_2 runs as two chained parts"""
         code = self.act.code
         parts = None
+        # the shortcut Conv_2 convolves the RAW input: its dynamic range comes out of GroupNorm_0's statistics pass (a bound on
+        # max |x| also bounds the FIR-resampled x: the taps of every phase are non-negative and sum to one)
+        need_amax = (self.in_ch != self.out_ch or self.up or self.down) and ops.unbounded_amax() is not None
+        amax = None
         if x2 is not None:
             if self.Conv_0.epilogue_folds() and self.Conv_2.kernel_size == 1:
                 parts = [x, x2]
-                h = self.GroupNorm_0((x, x2), code)
+                h = self.GroupNorm_0((x, x2), code, want_amax=need_amax)
             else:
                 x = torch.cat([x, x2], dim=1)
         if parts is None:
-            h = self.GroupNorm_0(x, code)
+            h = self.GroupNorm_0(x, code, want_amax=need_amax)
+        if need_amax:
+            h, amax = h
         if self.up:
             f = (lambda t: up_or_down_sampling.upsample_2d(t, self.fir_kernel, factor=2)) if self.fir else \
                 (lambda t: up_or_down_sampling.naive_upsample_2d(t, factor=2))
@@ -235,7 +241,7 @@ class ResnetBlockBigGANpp(nn.Module):
                 h = ops.affine_act(h, shift, ops.ACT_NONE, out=h)
         h = self.GroupNorm_1(h, code)
         if self.in_ch != self.out_ch or self.up or self.down:
-            x = self.Conv_2.forward_parts(parts) if parts is not None else self.Conv_2(x)
+            x = self.Conv_2.forward_parts(parts, in_amax=amax) if parts is not None else self.Conv_2(x, in_amax=amax)
         elif parts is not None:
             x = torch.cat(parts, dim=1)
         if fold:                                                   # (x + Conv_1(h)) [/ sqrt 2] in Conv_1's epilogue

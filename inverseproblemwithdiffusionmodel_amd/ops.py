@@ -522,18 +522,28 @@ def trilinear(x, size, out=None, accumulate=False, act=ACT_NONE):
 
 
 # ---- NCSN++ / predictor-corrector extras --------------------------------------------------------
-def groupnorm_coef(x, weight, bias, groups, eps=1e-6):
+def groupnorm_coef(x, weight, bias, groups, eps=1e-6, want_amax=False):
+    """-> coef [B, C, 3]; want_amax: -> (coef, per-image max |x| [B]) -- the maxima come out of the statistics pass (planes in
+    registers) plus one tiny reduction; where that pass is not the single-read kernel the input is measured separately"""
     x = _gpu(x, torch.float32, "x")
     B, C, H, W = x.shape
     coef = torch.empty((B, C, 3), dtype=torch.float32, device=x.device)
+    if want_amax:
+        planes = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        try:
+            call("ipdm_groupnorm_coef_f32", _ptr(x), _ptr(weight), _ptr(bias), _ptr(coef), B, C, H * W, groups, float(eps),
+                 _ptr(planes), _stream())
+            return coef, absmax_per_image(planes)
+        except _lib.IpdmUnsupported:
+            pass
     call("ipdm_groupnorm_coef_f32", _ptr(x), _ptr(weight), _ptr(bias), _ptr(coef), B, C, H * W, groups, float(eps),
-         _stream())
-    return coef
+         _ptr(None), _stream())
+    return (coef, absmax_per_image(x)) if want_amax else coef
 
 
-def groupnorm_act_cat(x1, x2, weight, bias, groups, eps=1e-6, act=ACT_NONE):
+def groupnorm_act_cat(x1, x2, weight, bias, groups, eps=1e-6, act=ACT_NONE, want_amax=False):
     """act(GroupNorm(torch.cat([x1, x2], dim=1))) without materialising the concatenation of the RAW tensors; falls back to
-    the concatenation where the two-source kernels do not apply"""
+    the concatenation where the two-source kernels do not apply.  want_amax: -> (out, per-image max over BOTH tensors [B])"""
     x1, x2 = _gpu(x1, torch.float32, "x1"), _gpu(x2, torch.float32, "x2")
     B, C1, H, W = x1.shape
     C2 = x2.shape[1]
@@ -541,13 +551,17 @@ def groupnorm_act_cat(x1, x2, weight, bias, groups, eps=1e-6, act=ACT_NONE):
         raise ValueError(f"groupnorm_act_cat: {tuple(x1.shape)} vs {tuple(x2.shape)}")
     coef = torch.empty((B, C1 + C2, 3), dtype=torch.float32, device=x1.device)
     out = torch.empty((B, C1 + C2, H, W), dtype=torch.float32, device=x1.device)
+    planes = torch.empty((B, C1 + C2), dtype=torch.float32, device=x1.device) if want_amax else None
     try:
         call("ipdm_groupnorm_coef_cat_f32", _ptr(x1), C1, _ptr(x2), C2, _ptr(weight), _ptr(bias), _ptr(coef), B, H * W, groups,
-             float(eps), _stream())
+             float(eps), _ptr(planes), _stream())
         call("ipdm_affine_act_cat_f32", _ptr(x1), C1, _ptr(x2), C2, _ptr(coef), _ptr(out), B, H * W, act, _stream())
-        return out
+        return (out, absmax_per_image(planes)) if want_amax else out
     except _lib.IpdmUnsupported:
         x = torch.cat([x1, x2], dim=1)
+        if want_amax:
+            c, am = groupnorm_coef(x, weight, bias, groups, eps, want_amax=True)
+            return affine_act(x, c, act), am
         return affine_act(x, groupnorm_coef(x, weight, bias, groups, eps), act)
 
 
