@@ -12,7 +12,7 @@ from scipy import integrate
 
 from . import sde_lib
 from .sde_lib import axpy_samples
-from .. import ops
+from .. import ops, sharding
 from ..models import utils as mutils
 from ..models.utils import from_flattened_numpy, to_flattened_numpy, get_score_fn
 
@@ -57,7 +57,7 @@ def _sample_norm_mean(v):
     if total is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         buf = torch.zeros(total, dtype=norms.dtype, device=norms.device)
         buf[_SHARD["lo"]:_SHARD["lo"] + norms.shape[0]] = norms
-        torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM)
+        sharding.all_reduce(buf)
         return buf.mean()
     return norms.mean()
 

@@ -4,10 +4,50 @@ weights), so the data path has NO collective: global sample ids are block-partit
 sample's Langevin noise is keyed by its global id (results do not depend on the number of GPUs), and
 the only exchange is one all-reduce(SUM) of seven moment planes at the end (RCCL over xGMI on GPUs, gloo in
 the CPU tests)."""
+import fcntl
 import os
 
 import torch
 import torch.distributed as dist
+
+# ---- ranks that SHARE one card (rehearsing N > 1 on a one-GPU box; never the production layout) -------------------------
+# Measured on MI355X (scripts/shared_card_probe.hip, profiles/r03_shared_card_probe.txt): while the direct 3x3 split-operand
+# convolution kernels of one HSA queue are resident, packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32, which hipcc
+# emits freely) of waves of ANOTHER queue on the same compute units return wrong values in their last 16 lanes -- 2 streams of
+# one process reproduce it in under a second, synthetic MFMA / LDS kernels do not, scalar fp32 and v_pk_fma_f32 victims are
+# never hit.  One process per GPU with one stream (the product layout: kernels of a stream never overlap) is unaffected.
+# IPDM_DEVICE_TURNS=1 makes ranks that share a card take turns: a rank computes only while it holds an exclusive file lock
+# and passes it on around every collective, so the rehearsal is bit-reproducible (tests/test_scripts_gpu.py).
+_TURN = {"fd": None, "held": False}
+
+
+def _take_turn():
+    if _TURN["fd"] is not None and not _TURN["held"]:
+        fcntl.flock(_TURN["fd"], fcntl.LOCK_EX)
+        _TURN["held"] = True
+
+
+def _pass_turn():
+    if _TURN["fd"] is not None and _TURN["held"]:
+        torch.cuda.synchronize()
+        fcntl.flock(_TURN["fd"], fcntl.LOCK_UN)
+        _TURN["held"] = False
+
+
+def barrier(last=False):
+    """last: the rank does no more GPU work afterwards (does not queue for another turn)"""
+    _pass_turn()
+    dist.barrier()
+    if not last:
+        _take_turn()
+
+
+def all_reduce(t, op=None):
+    """dist.all_reduce; ranks taking turns on a shared card pass the turn on while they wait in the collective"""
+    _pass_turn()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM if op is None else op)
+    _take_turn()
+
 
 
 def init_distributed():
@@ -26,6 +66,10 @@ def init_distributed():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if world > 1 and os.environ.get("IPDM_DEVICE_TURNS", "0") == "1" and _TURN["fd"] is None:
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ipdm_device_turn_{os.environ.get('MASTER_PORT', '0')}.lock")
+        _TURN["fd"] = os.open(path, os.O_CREAT | os.O_RDWR, 0o600)
+        _take_turn()
     return world, rank, device
 
 
@@ -39,7 +83,7 @@ def gather_samples(local, total, world, rank):
     real = torch.view_as_real(local) if local.is_complex() else local
     buf = torch.zeros((total,) + tuple(real.shape[1:]), dtype=real.dtype, device=real.device)
     buf[lo:hi] = real[: hi - lo]
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    all_reduce(buf)
     return torch.view_as_complex(buf) if local.is_complex() else buf
 
 
@@ -84,5 +128,5 @@ def all_reduce_posterior(local_samples, total):
     """one all-reduce of 7 float64 planes (896 KiB at 128x128); works without an initialised process group (N=1)."""
     m = moment_planes(local_samples)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(m, op=dist.ReduceOp.SUM)
+        all_reduce(m)
     return posterior_from_moments(m, total)

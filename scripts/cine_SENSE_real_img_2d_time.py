@@ -79,5 +79,5 @@ if __name__ == '__main__':
         if post is not None:
             torch.save({k: v.cpu() for k, v in post.items()}, os.path.join(a.save_dir, "posterior.pt"))
     if world > 1:
-        torch.distributed.barrier()
+        sharding.barrier(last=True)
         torch.distributed.destroy_process_group()

@@ -78,5 +78,5 @@ if __name__ == '__main__':
         torch.save(x, os.path.join(a.save_dir, "samples.pt"))
         torch.save(prior, os.path.join(a.save_dir, "prior.pt"))
     if world > 1:
-        torch.distributed.barrier()
+        sharding.barrier(last=True)
         torch.distributed.destroy_process_group()

@@ -32,7 +32,8 @@ def run_script(name, args, world=1, timeout=900):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         if world > 1:
             env.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                       MASTER_PORT=str(port), IPDM_DIST_BACKEND="gloo", IPDM_BENCH_DEVICE="0")
+                       MASTER_PORT=str(port), IPDM_DIST_BACKEND="gloo", IPDM_BENCH_DEVICE="0",
+                       IPDM_DEVICE_TURNS="1")       # ranks sharing the one card take turns (sharding.py)
         procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "scripts", name)] + [str(a) for a in args], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=REPO))
     outs = []
