@@ -29,7 +29,8 @@ def _take_turn():
 
 def _pass_turn():
     if _TURN["fd"] is not None and _TURN["held"]:
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         fcntl.flock(_TURN["fd"], fcntl.LOCK_UN)
         _TURN["held"] = False
 
@@ -66,11 +67,17 @@ def init_distributed():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if world > 1 and os.environ.get("IPDM_DEVICE_TURNS", "0") == "1" and _TURN["fd"] is None:
+    if world > 1 and os.environ.get("IPDM_DEVICE_TURNS", "0") == "1":
+        start_turns()
+    return world, rank, device
+
+
+def start_turns():
+    """ranks of this job take turns from here on (the lock file is keyed by the rendezvous port); idempotent"""
+    if _TURN["fd"] is None:
         path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ipdm_device_turn_{os.environ.get('MASTER_PORT', '0')}.lock")
         _TURN["fd"] = os.open(path, os.O_CREAT | os.O_RDWR, 0o600)
-        _take_turn()
-    return world, rank, device
+    _take_turn()
 
 
 def gather_samples(local, total, world, rank):

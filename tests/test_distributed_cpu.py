@@ -55,3 +55,39 @@ def test_single_process_needs_no_group():
     x = _samples(5)
     post = sharding.all_reduce_posterior(x, 5)
     np.testing.assert_allclose(post["mag_mean"].numpy(), np.abs(x.numpy()).mean(0), atol=1e-6)
+
+
+def _turn_worker(rank, world, port, out_dir):
+    """ranks that share a card take turns (sharding.start_turns): between collectives exactly one rank runs"""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["TMPDIR"] = out_dir
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from inverseproblemwithdiffusionmodel_amd import sharding
+    sharding.start_turns()
+    log = os.path.join(out_dir, "turns.log")
+    total = torch.zeros(3)
+    for step in range(3):
+        with open(log, "a") as f:                       # the section a rank runs while it holds the turn
+            f.write(f"enter {rank} {step}\n")
+            f.flush()
+            time.sleep(0.05)
+            f.write(f"leave {rank} {step}\n")
+        t = torch.zeros(3)
+        t[step] = rank + 1.0
+        sharding.all_reduce(t)                          # passes the turn on while waiting, queues for it afterwards
+        total += t
+    sharding.barrier(last=True)
+    if rank == 0:
+        torch.save(total, os.path.join(out_dir, "total.pt"))
+    dist.destroy_process_group()
+
+
+def test_shared_card_turns_world2(tmp_path):
+    mp.spawn(_turn_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert torch.equal(torch.load(os.path.join(tmp_path, "total.pt")), torch.full((3,), 3.0))
+    lines = open(os.path.join(tmp_path, "turns.log")).read().split("\n")[:-1]
+    assert len(lines) == 12
+    for a, b in zip(lines[0::2], lines[1::2]):          # sections never interleave: every enter is followed by its own leave
+        assert a.startswith("enter") and b == a.replace("enter", "leave"), lines
