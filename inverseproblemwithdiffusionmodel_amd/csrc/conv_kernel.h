@@ -56,8 +56,8 @@ __device__ __forceinline__ void split2_pk(float v0, float v1, unsigned& hp, unsi
 // so that their range contract is the direct kernels' |x| < 65504; the epilogue's inverse weight scale carries the 4):
 // v_fma_mixlo_f16 / v_fma_mixhi_f16 (f16(v * s), exact scaling), two v_fma_mix_f32 (v * s - f32(h), exact), v_cvt_pk_f16_f32
 __device__ __forceinline__ void split2_pk_scaled(float v0, float v1, float s, unsigned& hp, unsigned& lp) {
-  unsigned h = 0;
-  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(h) : "v"(v0), "v"(s));
+  unsigned h;                              // mixlo defines the low half (the high half, kept from whatever the register held,
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(v0), "v"(s));        // is overwritten by mixhi): no zero-initialising move
   asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(v1), "v"(s));
   hp = h;
   float r0, r1;

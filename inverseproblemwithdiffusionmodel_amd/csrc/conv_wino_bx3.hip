@@ -783,8 +783,10 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       for (int rr = 0; rr < 4; ++rr) {
         const float2 q1 = *reinterpret_cast<const float2*>(rp + rr * RC4 + 2);
         const float e = rp[rr * RC4 + edge];
-        const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q1.y), 0x111, 0xf, 0xf, false));
-        const float right = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q1.x), 0x101, 0xf, 0xf, false));
+        // (bound_ctrl form, no `old` operand: the row-end lanes, whose source lane does not exist, take `e` below -- with an
+        //  old value hipcc materialises a zero per DPP move and cannot fold the move into the select)
+        const float left = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q1.y), 0x111, 0xf, 0xf, true));
+        const float right = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q1.x), 0x101, 0xf, 0xf, true));
         dreg[rr * 4 + 0] = first ? e : left;
         dreg[rr * 4 + 1] = q1.x;
         dreg[rr * 4 + 2] = q1.y;
@@ -919,6 +921,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   Geo cur_g = geo_of(tile);
   uint4 afr[2][2][NPC];
   load_A(afr[0], p0, cur_g.c0, cur_g.co_tile);
+  if constexpr (WPRIV) load_A(afr[1], p0 + 1, cur_g.c0, cur_g.co_tile);
   hx_scales_of(cur_g.b, hx_in, hx_out);
   set_dma_geo(cur_g);
   // workgroup barrier for LDS data only: __syncthreads() also drains vmcnt, i.e. would wait for a DMA just issued
@@ -975,9 +978,8 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
         // are dealt over the four MFMA steps; the chunk ends with the V-stage barrier (LDS only: no vmcnt drain).
         uint4 bsh[2][2];
         float va[16], vb[16];
-        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
-        load_A(afr[1], p0 + 1, cur_g.c0 + ch, cur_g.co_tile);
-        read_patch_to(va, 2 * wave);
+        __builtin_amdgcn_s_waitcnt(0x0F74);                     // vmcnt(4): everything but the four youngest -- position p0+1's
+        read_patch_to(va, 2 * wave);                            // fragments, requested at the end of the previous chunk
         read_patch_to(vb, 2 * wave + 1);
         load_Bh(bsh[0], cur, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -1016,6 +1018,9 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
           __builtin_amdgcn_sched_barrier(0);
           IPDM_TR(1 + st);
         });
+        // position p0+1's fragments of the NEXT chunk, the moment their registers are free (the last MFMA that reads them has
+        // issued): a barrier wait and the next chunk's patch reads earlier than at its top, where step 2 stalled ~1 k cycles on them
+        load_A(afr[1], p0 + 1, a_chunk, a_cot);
       } else if constexpr (HX) {
         // f16x2 chunk.  With three MFMAs per product the matrix work of a chunk (48 MFMAs per wave) no longer covers a DMA
         // round trip issued a quarter chunk in: the raw patches are read into registers FIRST, the barrier that frees the raw

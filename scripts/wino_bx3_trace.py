@@ -15,17 +15,20 @@ _lib.lib.ipdm_debug_set_stamp_buffer(_lib.P(buf.data_ptr()))
 ops.conv2d_wino_bx3(x, U); torch.cuda.synchronize()
 _lib.lib.ipdm_debug_set_stamp_buffer(_lib.P(0))
 t = buf.cpu()[nblk * 4:].view(nblk, 8, 8).double()
-names = ["B0 read+split", "step0 (xform)", "mid barrier", "step1 (dma)", "step2", "step3", "dma wait", "end barrier"]
-# stamp order in tr: 0 start, 1 after st0, 5 after mid barrier, 2 after st1, 3 after st2, 4 after st3, 6 after dma wait, 7 after barrier
-seq = [0, 1, 5, 2, 3, 4, 6, 7]
-d = torch.stack([t[:, :, seq[i + 1]] - t[:, :, seq[i]] for i in range(7)], dim=-1)   # [blk, wave, 7]
+# stamps (conv_wino_bx3.hip, IPDM_TR): 0 chunk start, 5 patches in registers (after the fragment / DMA wait and the LDS reads),
+# 1..4 after MFMA steps 0..3, 7 after the chunk's barrier; 6 (DMA wait) exists only in the shared-raw-stage forms
+wave_private = bool((t[:, :, 6] == 0).all())
+seq = [0, 5, 1, 2, 3, 4, 7] if wave_private else [0, 1, 5, 2, 3, 4, 6, 7]
+names = (["wait+patch reads", "step0", "step1", "step2", "step3", "end barrier"] if wave_private else
+         ["st0(+B0 split)", "mid barrier", "step1 (dma)", "step2", "step3", "dma wait", "end barrier"])
+d = torch.stack([t[:, :, seq[i + 1]] - t[:, :, seq[i]] for i in range(len(seq) - 1)], dim=-1)   # [blk, wave, segments]
 med = d.median(dim=0).values
-print("median cycles per segment, per wave (rows = wave 0..7):")
-print("   " + "  ".join(f"{n:>14s}" for n in ["st0(+B0 split)", "mid barrier", "step1 (dma)", "step2", "step3", "dma wait", "end barrier"]))
+print("median cycles per segment, per wave (rows = wave 0..7; waves w and w+4 share a SIMD):")
+print("   " + "  ".join(f"{n:>16s}" for n in names))
 for wv in range(8):
-    print(f"w{wv} " + "  ".join(f"{med[wv, i]:14.0f}" for i in range(7)), f"  total {med[wv].sum():.0f}")
+    print(f"w{wv} " + "  ".join(f"{med[wv, i]:16.0f}" for i in range(len(names))), f"  total {med[wv].sum():.0f}")
 for blk in (0, 100):
     base = t[blk, :, 0].min()
-    print(f"workgroup {blk}: stamps relative to the first wave's chunk start (start, st0, mid-barrier, st1, st2, st3, dma, end-barrier)")
+    print(f"workgroup {blk}: stamps relative to the first wave's chunk start ({', '.join(['start'] + names)})")
     for wv in range(8):
         print(f"w{wv} " + " ".join(f"{t[blk, wv, k] - base:7.0f}" for k in seq))
