@@ -24,5 +24,6 @@ for ci, co, hw in [(128, 128, 128), (256, 256, 64)]:
     per_wg = tiles / t.shape[0]
     nch = ci // 16
     mfma_bound = (48 if os.environ.get('FMT', 'hx2') == 'hx2' else 96) * 32
+    print(f"    last tile's epilogue (t3 - t2): median {(t[:, 3] - t[:, 2]).median():.0f} cycles; prologue (t1 - t0): {(t[:, 1] - t[:, 0]).median():.0f}")
     print(f"{ci}->{co}@{hw}: {ms * 1e3:.0f} us, {t.shape[0]} workgroups x {per_wg:.1f} tiles; cycles/WG median {tot.median():.0f} max {tot.max():.0f}; "
           f"per (tile, chunk) {tot.median() / per_wg / nch:.0f} (MFMA-bound {mfma_bound}); implied clock {tot.max() / ms / 1e6:.2f} GHz")
