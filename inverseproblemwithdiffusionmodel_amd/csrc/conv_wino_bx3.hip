@@ -946,8 +946,15 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
 #ifdef IPDM_WBX3_TRACE
   unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // step timeline of chunk 2 of the second tile (diagnostic build)
 #define IPDM_TR(k) if (a.dbg && trace_now) tr[k] = __builtin_amdgcn_s_memtime()
+  unsigned long long te[18] = {};                              // epilogue timeline of the second tile: start, then per round
+  int tiles_done = 0;                                           //   after the exchange stores / barrier / transform+stores / barrier
+#define IPDM_TE(k) if (a.dbg && tiles_done == 1) te[k] = __builtin_amdgcn_s_memtime()
+  unsigned long long tf[6] = {};                               // inside round 1's transform phase
+#define IPDM_TF(k) if (a.dbg && tiles_done == 1) tf[k] = __builtin_amdgcn_s_memtime()
 #else
+#define IPDM_TF(k)
 #define IPDM_TR(k)
+#define IPDM_TE(k)
 #endif
   while (true) {
     const int next_tile = tile + S;
@@ -1163,6 +1170,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     // ---- epilogue of this tile in the stage its last chunk was read from (the other stage and the raw stage already
     //      hold the next tile); rounds over (channel tile c, tile group tg) ----
     float* ms = lds + ((g - 1) & 1) * X_V_ELEMS;              // M[pos 16][co 32][tile 32]
+    IPDM_TE(0);
     const int etile = tid & 31, ecg = tid >> 5;               // this thread: tile, channels 2*ecg, 2*ecg+1 of the 32
     const int co0 = cur_g.co_tile * X_CO;
     // bias and residual of a round are fetched ONE ROUND AHEAD (round 0: before the first exchange): issued next to their
@@ -1174,18 +1182,26 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     float biasv[AHEAD ? 2 : 1][2];
     [[maybe_unused]] float scalev[AHEAD ? 2 : 1][2];            // f16x2: the channel's inverse weight scale (blob tail)
     const float* const scale_p = HX ? reinterpret_cast<const float*>(wq + 16 * pos_stride) : a.wt;
-    auto out_index = [&](int c, int tg, int i, int ii) -> size_t {
-      if constexpr (POLY) {                                     // -> the first of the row's two outputs; the second: + d
-        int py, px;
-        tile_origin(tg * 32 + etile, py, px);
-        return ((size_t)cur_g.b * a.Cout + co0 + c * 32 + ecg * 2 + i) * HW + (size_t)(py + pd * ii) * a.W + px;
-      }
-      const int T = tg * 32 + etile;
-      const int oy = cur_g.y0 + 2 * (T / TX), ox = cur_g.x0 + 2 * (T % TX);
-      const int co = co0 + c * 32 + ecg * 2 + i;
-      if constexpr (POOL) return (((size_t)cur_g.b * a.Cout + co) * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1);
-      const size_t part = KSP ? (size_t)cur_g.ks * a.B * a.Cout * HW : 0;      // this K part's plane set of the workspace
-      return part + ((size_t)cur_g.b * a.Cout + co) * HW + (size_t)(oy + ii) * a.W + ox;
+    // address of an output = [one 64-bit base per tile pass and tensor, scalar] + [32-bit byte offset: a scalar term per (round,
+    // channel of the pair, row) + this thread's own term, fixed for the whole launch] -- the `global_* v, v, s[base]` form, one
+    // vector add per address (the four-term element index recomputed per address was ~12 vector instructions, five of them
+    // quarter-rate 64-bit multiplies: a third of the epilogue's issue time)
+    [[maybe_unused]] const int oH = POOL ? a.H >> 1 : a.H, oW = POOL ? a.W >> 1 : a.W;   // dimensions of the written tensor
+    [[maybe_unused]] constexpr int rstep = POOL ? 1 : 2;                                 // its rows / columns per tile
+    [[maybe_unused]] const size_t tile_base =
+        ((KSP ? (size_t)cur_g.ks * a.B * a.Cout * HW : 0) +                              // this K part's plane set of the workspace
+         ((size_t)cur_g.b * a.Cout + co0) * ((size_t)oH * oW) + (size_t)(POOL ? cur_g.y0 >> 1 : cur_g.y0) * oW +
+         (POOL ? cur_g.x0 >> 1 : cur_g.x0)) * 4;
+    [[maybe_unused]] unsigned eoff4 = 4u * (unsigned)((ecg * 2) * (oH * oW) + rstep * (etile / TX) * oW + rstep * (etile % TX));
+    // (opaque per tile: hipcc otherwise hoists all sixteen sums below out of the tile loop and spills them across the chunk loop)
+    asm volatile("" : "+v"(eoff4));
+    [[maybe_unused]] auto boff = [&](int c, int tg, int i, int ii) -> unsigned {
+      return 4u * (unsigned)((c * 32 + i) * (oH * oW) + (rstep * (tg * 32 / TX) + ii) * oW) + eoff4;
+    };
+    auto out_index = [&](int c, int tg, int i, int ii) -> size_t {   // POLY only: element index of the row's first output; second: + d
+      int py, px;
+      tile_origin(tg * 32 + etile, py, px);
+      return ((size_t)cur_g.b * a.Cout + co0 + c * 32 + ecg * 2 + i) * HW + (size_t)(py + pd * ii) * a.W + px;
     };
     auto in_range = [&](int tg) {
       if constexpr (POLY) return true;                          // exactly 64 tiles per image
@@ -1197,6 +1213,9 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     const bool has_res = a.residual != nullptr, has_bias = a.bias != nullptr;
     const float* const res_p = has_res ? a.residual : a.wt;
     const float* const bias_p = has_bias ? a.bias : a.wt;
+    [[maybe_unused]] const char* const res_b = reinterpret_cast<const char*>(res_p) + (has_res ? tile_base : 0);
+    [[maybe_unused]] char* const out_b = reinterpret_cast<char*>(a.out) + tile_base;           // (dereferenced only where non-null)
+    [[maybe_unused]] char* const act_b = reinterpret_cast<char*>(a.out_act) + tile_base;
     auto prefetch = [&](auto rc) {
       constexpr int rnd = decltype(rc)::value;
       constexpr int c = rnd >> 1, tg = rnd & 1, bf = AHEAD ? rnd & 1 : 0;
@@ -1207,10 +1226,14 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
         if constexpr (HX) scalev[bf][i] = scale_p[co0 + c * 32 + ecg * 2 + i] * hx_out;
 #pragma unroll
         for (int ii = 0; ii < NR; ++ii) {
-          const size_t o = res_ok ? out_index(c, tg, i, ii) : 0;
-          if constexpr (POOL) resv[bf][i][ii] = make_float2(res_p[o], 0.f);
-          else if constexpr (POLY) resv[bf][i][ii] = make_float2(res_p[o], res_p[o + (res_ok ? pd : 0)]);
-          else resv[bf][i][ii] = *reinterpret_cast<const float2*>(res_p + o);
+          if constexpr (POLY) {
+            const size_t o = res_ok ? out_index(c, tg, i, ii) : 0;
+            resv[bf][i][ii] = make_float2(res_p[o], res_p[o + (res_ok ? pd : 0)]);
+          } else {
+            const unsigned ob = res_ok ? boff(c, tg, i, ii) : 0u;
+            if constexpr (POOL) resv[bf][i][ii] = make_float2(*reinterpret_cast<const float*>(res_b + ob), 0.f);
+            else resv[bf][i][ii] = *reinterpret_cast<const float2*>(res_b + ob);
+          }
         }
       }
     };
@@ -1226,7 +1249,9 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
           const int col = (rr & 3) + 8 * (rr >> 2) + 4 * h;
           ms[((p0 + pi) * 32 + col) * 32 + j] = acc[pi][c][tg][rr];
         }
+      IPDM_TE(1 + 4 * rnd);
       __syncthreads();
+      IPDM_TE(2 + 4 * rnd);
       if constexpr (AHEAD && rnd < 3) prefetch(std::integral_constant<int, rnd + 1>{});
       constexpr int NSV = POOL ? 1 : 4;
       [[maybe_unused]] float sv[2][NSV];                      // STATS: this thread's stored values of the round
@@ -1236,6 +1261,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
 #pragma unroll
           for (int k = 0; k < NSV; ++k) sv[i][k] = 0.f;
       }
+      if constexpr (rnd == 1) { IPDM_TF(0); }
       if (in_range(tg)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1249,6 +1275,12 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
             tt[0][qq] = m[0 * 4 + qq] + m[1 * 4 + qq] + m[2 * 4 + qq];
             tt[1][qq] = m[1 * 4 + qq] - m[2 * 4 + qq] - m[3 * 4 + qq];
           }
+#ifdef IPDM_WBX3_TRACE
+          if constexpr (rnd == 1) {
+            asm volatile("" : "+v"(tt[0][0]), "+v"(tt[1][3]));
+            if (i == 0) { IPDM_TF(1); } else { IPDM_TF(3); }
+          }
+#endif
           const float bias = has_bias ? biasv[bf][i] : 0.f;
           if constexpr (POOL) {
             // ConvMeanPool: (y[::2,::2] + y[1::2,::2] + y[::2,1::2] + y[1::2,1::2]) / 4 in the reference's order; the
@@ -1263,12 +1295,12 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
               y00 += bias; y01 += bias; y10 += bias; y11 += bias;
             }
             float v = (((y00 + y10) + y01) + y11) * 0.25f;
-            const size_t o = out_index(c, tg, i, 0);
+            const unsigned ob = boff(c, tg, i, 0);
             if (has_res) v += resv[bf][i][0].x;
             v *= a.out_scale;
             if constexpr (STATS) sv[i][0] = v;
-            if (a.out) a.out[o] = v;
-            if (a.out_act) a.out_act[o] = a.act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, a.act_out);
+            if (a.out) *reinterpret_cast<float*>(out_b + ob) = v;
+            if (a.out_act) *reinterpret_cast<float*>(act_b + ob) = a.act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, a.act_out);
           } else {
 #pragma unroll
           for (int ii = 0; ii < 2; ++ii) {
@@ -1280,7 +1312,10 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
               y0v += bias;
               y1v += bias;
             }
-            const size_t o = out_index(c, tg, i, ii);
+            [[maybe_unused]] size_t o = 0;
+            [[maybe_unused]] unsigned ob = 0;
+            if constexpr (POLY) o = out_index(c, tg, i, ii);
+            else ob = boff(c, tg, i, ii);
             if (has_res) {
               y0v += resv[bf][i][ii].x;
               y1v += resv[bf][i][ii].y;
@@ -1297,7 +1332,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
                 a.out[o + pd] = y1v;
               }
             } else {
-              if (a.out) *reinterpret_cast<float2*>(a.out + o) = make_float2(y0v, y1v);
+              if (a.out) *reinterpret_cast<float2*>(out_b + ob) = make_float2(y0v, y1v);
             }
             if (a.out_act) {
               const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
@@ -1306,11 +1341,16 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
                 a.out_act[o] = e0;
                 a.out_act[o + pd] = e1;
               } else {
-                *reinterpret_cast<float2*>(a.out_act + o) = make_float2(e0, e1);
+                *reinterpret_cast<float2*>(act_b + ob) = make_float2(e0, e1);
               }
             }
           }
           }
+#ifdef IPDM_WBX3_TRACE
+          if constexpr (rnd == 1) {
+            if (i == 0) { IPDM_TF(2); } else { IPDM_TF(4); }
+          }
+#endif
         }
       }
       if constexpr (STATS) {
@@ -1348,8 +1388,13 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
           }
         }
       }
+      IPDM_TE(3 + 4 * rnd);
       __syncthreads();                                        // M is rewritten by the next round / the next tile's V
+      IPDM_TE(4 + 4 * rnd);
     });
+#ifdef IPDM_WBX3_TRACE
+    ++tiles_done;
+#endif
     if (!has_next) break;
     zero_acc();
     tile = next_tile;
@@ -1368,6 +1413,12 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       unsigned long long* d8 = a.dbg + (size_t)gridDim.x * 4 + ((size_t)blockIdx.x * 8 + wave) * 8;
 #pragma unroll
       for (int k = 0; k < 8; ++k) d8[k] = tr[k];
+      unsigned long long* d18 = a.dbg + (size_t)gridDim.x * (4 + 64) + ((size_t)blockIdx.x * 8 + wave) * 18;
+#pragma unroll
+      for (int k = 0; k < 18; ++k) d18[k] = te[k];
+      unsigned long long* d6 = a.dbg + (size_t)gridDim.x * (4 + 64 + 8 * 18) + ((size_t)blockIdx.x * 8 + wave) * 6;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) d6[k] = tf[k];
     }
 #endif
   }

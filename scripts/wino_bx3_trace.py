@@ -8,13 +8,15 @@ B, ci, co, hw = 28, 128, 128, 128
 x = torch.randn(B, ci, hw, hw, device="cuda"); w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
 U = ops.conv_wino_bx3_weight(w, fmt=os.environ.get('FMT', 'hx2'))
 nblk = 256                                       # persistent kernel: one workgroup per CU
-buf = torch.zeros(nblk * 4 + nblk * 64, dtype=torch.int64, device="cuda")
+buf = torch.zeros(nblk * 4 + nblk * 64 + nblk * 8 * 18 + nblk * 8 * 6, dtype=torch.int64, device="cuda")
 for _ in range(3): ops.conv2d_wino_bx3(x, U)
 torch.cuda.synchronize()
 _lib.lib.ipdm_debug_set_stamp_buffer(_lib.P(buf.data_ptr()))
 ops.conv2d_wino_bx3(x, U); torch.cuda.synchronize()
 _lib.lib.ipdm_debug_set_stamp_buffer(_lib.P(0))
-t = buf.cpu()[nblk * 4:].view(nblk, 8, 8).double()
+t = buf.cpu()[nblk * 4:nblk * 68].view(nblk, 8, 8).double()
+te = buf.cpu()[nblk * 68:nblk * (68 + 144)].view(nblk, 8, 18).double()
+tf = buf.cpu()[nblk * (68 + 144):].view(nblk, 8, 6).double()
 # stamps (conv_wino_bx3.hip, IPDM_TR): 0 chunk start, 5 patches in registers (after the fragment / DMA wait and the LDS reads),
 # 1..4 after MFMA steps 0..3, 7 after the chunk's barrier; 6 (DMA wait) exists only in the shared-raw-stage forms
 wave_private = bool((t[:, :, 6] == 0).all())
@@ -32,3 +34,16 @@ for blk in (0, 100):
     print(f"workgroup {blk}: stamps relative to the first wave's chunk start ({', '.join(['start'] + names)})")
     for wv in range(8):
         print(f"w{wv} " + " ".join(f"{t[blk, wv, k] - base:7.0f}" for k in seq))
+
+# epilogue of the second tile: stamp 0 start, then per round (exchange stores issued, barrier, transform + global stores issued, barrier)
+if bool((te[:, :, 0] != 0).all()):
+    de = te[:, :, 1:] - te[:, :, :-1]
+    mede = de.median(dim=0).values
+    print("epilogue, median cycles per segment and wave; rounds 0..3 x (exchange stores, barrier, reads+transform+stores, barrier):")
+    for wv in range(8):
+        print(f"w{wv} " + " | ".join(" ".join(f"{mede[wv, 4 * r + k]:6.0f}" for k in range(4)) for r in range(4)), f"  total {(te[:, wv, 16] - te[:, wv, 0]).median():.0f}")
+if bool((tf[:, :, 0] != 0).all()):
+    print("round 1's transform phase: phase start -> channel 0: reads + first sums, second sums + stores issued; channel 1: the same")
+    df = (tf[:, :, 1:5] - tf[:, :, 0:4]).median(dim=0).values
+    for wv in range(8):
+        print(f"w{wv} " + " ".join(f"{df[wv, k]:6.0f}" for k in range(4)))
