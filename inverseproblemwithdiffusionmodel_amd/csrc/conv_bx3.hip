@@ -378,12 +378,16 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
     gy = gy < a.H ? gy : a.H - 1;
     gx = gx < a.W ? gx : a.W - 1;
     const int cob = co0 + (wco * NCT + m) * 32 + 4 * h;
-    const size_t pb = has_res ? ((size_t)b * a.Cout * a.D + z) * HW + (size_t)gy * a.W + gx : 0;
+    // channel cob + dco clamped to Cout - 1 (ragged last tile), as a 32-bit offset from channel cob's plane: the constant dco
+    // times the plane stride is scalar, only the clamp value is per-thread (a per-element 64-bit product cost three quarter-rate
+    // multiplies per residual value)
+    const int cs32 = has_res ? (int)co_stride : 0;              // D * H * W < 2^26 (launcher)
+    const int lim = a.Cout - 1 - cob, limoff = lim * cs32;
+    const float* const rp = res_p + (has_res ? (((size_t)b * a.Cout + cob) * a.D + z) * HW + (size_t)gy * a.W + gx : 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      int co = cob + (r & 3) + 8 * (r >> 2);
-      co = co < a.Cout ? co : a.Cout - 1;
-      rv[q & 1][r] = res_p[pb + co * co_stride];
+      const int dco = (r & 3) + 8 * (r >> 2);
+      rv[q & 1][r] = rp[(ptrdiff_t)(dco <= lim ? dco * cs32 : limoff)];
     }
   };
 #pragma unroll
@@ -404,13 +408,16 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
     pixel_of(n, gy, gx);
     if (gy < a.H && gx < a.W) {
       const int cob = co0 + (wco * NCT + m) * 32 + 4 * h;      // channel of r = 0; r adds (r & 3) + 8 * (r >> 2)
-      const size_t ob = (((size_t)b * a.Cout + cob) * a.D + z) * HW + (size_t)gy * a.W + gx;
-      const size_t os = (size_t)a.D * HW;
+      size_t ob = (((size_t)b * a.Cout + cob) * a.D + z) * HW + (size_t)gy * a.W + gx;
+      // (opaque: hipcc otherwise folds the channel step back into the product chain and recomputes the whole 64-bit index --
+      //  six quarter-rate multiplies -- for every one of the 16 values; the step itself is a scalar, D * H * W < 2^26: launcher)
+      asm volatile("" : "+v"(ob));
+      const unsigned os32 = (unsigned)(a.D * HW);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int dco = (r & 3) + 8 * (r >> 2);
         if (cob + dco < a.Cout) {
-          const size_t o = ob + dco * os;
+          const size_t o = ob + (size_t)((unsigned)dco * os32);
           float v;
           if constexpr (PW == 16) v = tot[m][n][r];
           else v = acc[m][n][r];
@@ -445,7 +452,7 @@ int launch_bx3(ConvArgs a, hipStream_t s) {
   a.tiles_y = (a.H + C::PH - 1) / C::PH;
   a.co_tiles = (a.Cout + C::CO_T - 1) / C::CO_T;
   const int64_t nblk = (int64_t)a.B * a.D * a.tiles_x * a.tiles_y * a.co_tiles * a.ksplit;
-  if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
+  if (nblk > 0x7fffffff || (int64_t)a.D * a.H * a.W >= (1 << 26)) return IPDM_EUNSUPPORTED;   // (32-bit plane offsets in the epilogue)
   auto kern = conv_bx3_kernel<HX, NCT, NPT, WCO, WPX, PW, DMAX, KS, FAST>;
   static bool attr_set = false;
   if (!attr_set) {
