@@ -8,7 +8,7 @@ B, ci, co, hw = 28, 128, 128, 128
 x = torch.randn(B, ci, hw, hw, device="cuda"); w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
 U = ops.conv_wino_bx3_weight(w, fmt=os.environ.get('FMT', 'hx2'))
 nblk = 256                                       # persistent kernel: one workgroup per CU
-buf = torch.zeros(nblk * 4 + nblk * 64 + nblk * 8 * 18 + nblk * 8 * 6, dtype=torch.int64, device="cuda")
+buf = torch.zeros(nblk * 4 + nblk * 64 + nblk * 8 * 18 + nblk * 8 * 6 + nblk * 8 * 18, dtype=torch.int64, device="cuda")
 for _ in range(3): ops.conv2d_wino_bx3(x, U)
 torch.cuda.synchronize()
 _lib.lib.ipdm_debug_set_stamp_buffer(_lib.P(buf.data_ptr()))
@@ -16,7 +16,8 @@ ops.conv2d_wino_bx3(x, U); torch.cuda.synchronize()
 _lib.lib.ipdm_debug_set_stamp_buffer(_lib.P(0))
 t = buf.cpu()[nblk * 4:nblk * 68].view(nblk, 8, 8).double()
 te = buf.cpu()[nblk * 68:nblk * (68 + 144)].view(nblk, 8, 18).double()
-tf = buf.cpu()[nblk * (68 + 144):].view(nblk, 8, 6).double()
+tf = buf.cpu()[nblk * (68 + 144):nblk * (68 + 144 + 48)].view(nblk, 8, 6).double()
+tq = buf.cpu()[nblk * (68 + 144 + 48):].view(nblk, 8, 18).double()
 # stamps (conv_wino_bx3.hip, IPDM_TR): 0 chunk start, 5 patches in registers (after the fragment / DMA wait and the LDS reads),
 # 1..4 after MFMA steps 0..3, 7 after the chunk's barrier; 6 (DMA wait) exists only in the shared-raw-stage forms
 wave_private = bool((t[:, :, 6] == 0).all())
@@ -47,3 +48,10 @@ if bool((tf[:, :, 0] != 0).all()):
     df = (tf[:, :, 1:5] - tf[:, :, 0:4]).median(dim=0).values
     for wv in range(8):
         print(f"w{wv} " + " ".join(f"{df[wv, k]:6.0f}" for k in range(4)))
+if bool((tq[:, :, 0] != 0).all()):
+    nch = ci // 16
+    w0 = tq[:, 0, :]
+    seg = [(w0[:, k + 1] - w0[:, k]).median().item() for k in range(nch - 1)] + [(w0[:, 16] - w0[:, nch - 1]).median().item()]
+    print("second tile, wave 0: cycles of chunk 0 .. %d:" % (nch - 1), " ".join(f"{v:.0f}" for v in seg),
+          f"| epilogue {(w0[:, 17] - w0[:, 16]).median().item():.0f} | whole tile {(w0[:, 17] - w0[:, 0]).median().item():.0f}")
+    print(f"first tile's epilogue end -> second tile's first chunk start: {(w0[:, 0] - te[:, 0, 16]).median().item():.0f} cycles (te of tile 1 is taken on tile index 1: see source)")
