@@ -494,8 +494,15 @@ static int bx3_forced_cfg() {
 int conv_bx3_dispatch(const ConvArgs& a, int ks, hipStream_t s) {
   const int f = bx3_forced_cfg();
   if (a.W <= 16) {
-    if (a.dil > 1 && ks == 3) return launch_bx3_cfg<1, 2, 2, 2, 16, 4>(a, ks, s);    // 64 co x (8 x 16) px
-    return launch_bx3_cfg<1, 2, 2, 2, 16, 1>(a, ks, s);
+    // 128 output channels per workgroup (a wave: 32 channels x all four 32-pixel tiles) where that still leaves two workgroups
+    // per CU: a weight fragment then feeds 12 MFMAs instead of 6 -- the 64-channel form draws ~42 B/clk/CU of fragments from L2,
+    // more than a CU gets (config 4's 3-D layers: 0.722 -> 0.677 s per level).  Same K order per output: same bits.
+    const int64_t wgs128 = (int64_t)a.B * a.D * ((a.H + 7) / 8) * ((a.W + 15) / 16) * ((a.Cout + 127) / 128) * a.ksplit;
+    const bool wide_co = f == 3 || (f != 4 && a.Cout >= 128 && wgs128 >= 512);
+    if (a.dil > 1 && ks == 3)
+      return wide_co ? launch_bx3_cfg<1, 4, 4, 1, 16, 4>(a, ks, s) : launch_bx3_cfg<1, 2, 2, 2, 16, 4>(a, ks, s);
+    return wide_co ? launch_bx3_cfg<1, 4, 4, 1, 16, 1>(a, ks, s)                     // 128 co x (8 x 16) px
+                   : launch_bx3_cfg<1, 2, 2, 2, 16, 1>(a, ks, s);                    //  64 co x (8 x 16) px
   }
   if (a.dil > 1 && ks == 3) return launch_bx3_cfg<1, 4, 2, 2, 32, 4>(a, ks, s);
   if (f == 1) return launch_bx3_cfg<1, 2, 1, 4, 32, 1>(a, ks, s);                    // 32 co x 256 px

@@ -1221,3 +1221,30 @@ def test_conv_wino_bx3_pooled_epilogue(ops, B, Cin, Cout, H, W, fmt):
     assert only_act[0] is None and torch.equal(only_act[1], out_act)
     with pytest.raises(Exception):
         ops.conv2d_wino_bx3(x.cuda()[:, :, :16, :16].contiguous(), U, b.cuda(), pool2=True)     # small-image kernels: unsupported
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["hx2", "bx3"])
+@pytest.mark.parametrize("dil", [1, 2])
+def test_conv_bx3_channel_tile_choice_keeps_the_bits(ops, fmt, dil):
+    """16-pixel layers: the direct split-operand kernel picks 128 output channels per workgroup when the launch is large
+    enough and 64 otherwise (conv_bx3_dispatch) -- a sample's result must not depend on how many samples share the launch
+    (sharding relies on it): 512 images at once (128-channel tiles) == the same images 8 at a time (64-channel tiles),
+    2-D and 3-D (depth folded into K), bit for bit"""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(512, 32, 8, 12, generator=g).cuda()
+    w = (torch.randn(160, 32, 3, 3, generator=g) * 0.1).cuda()          # 160: a ragged second 128-channel tile
+    bias = torch.randn(160, generator=g).cuda()
+    pk = ops.conv_bx3_weight(w, fmt=fmt)
+    big = ops.conv_bx3(x, pk, bias, dilation=dil)
+    small = torch.cat([ops.conv_bx3(x[i:i + 8].contiguous(), pk, bias, dilation=dil) for i in range(0, 512, 8)])
+    assert torch.equal(big, small)
+    ref = torch.nn.functional.conv2d(x[:4].double(), w.double(), bias.double(), padding=dil, dilation=dil)
+    assert (big[:4].double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+    if dil == 1:
+        xv = torch.randn(64, 16, 8, 8, 12, generator=g).cuda()          # 64 volumes x 8 slices: 128-channel tiles
+        wv = (torch.randn(128, 16, 3, 3, 3, generator=g) * 0.1).cuda()
+        pv = ops.conv_bx3_weight(wv, fmt=fmt)
+        bigv = ops.conv3d(xv, pv)
+        smallv = torch.cat([ops.conv3d(xv[i:i + 2].contiguous(), pv) for i in range(0, 64, 2)])
+        assert torch.equal(bigv, smallv)
