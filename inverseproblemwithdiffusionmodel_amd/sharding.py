@@ -14,8 +14,8 @@ import torch.distributed as dist
 # Measured on MI355X (scripts/shared_card_probe.hip, profiles/r03_shared_card_probe.txt): while the direct 3x3 split-operand
 # convolution kernels of one HSA queue are resident, packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32, which hipcc
 # emits freely) of waves of ANOTHER queue on the same compute units return wrong values in their last 16 lanes -- 2 streams of
-# one process reproduce it in under a second, synthetic MFMA / LDS kernels do not, scalar fp32 and v_pk_fma_f32 victims are
-# never hit.  One process per GPU with one stream (the product layout: kernels of a stream never overlap) is unaffected.
+# one process reproduce it in under a second, and so does a 30-line synthetic kernel (ds_read_b128 -> chained f16 MFMAs) in place of
+# the convolution; scalar fp32 and v_pk_fma_f32 victims are never hit.  One process per GPU with one stream (the product layout: kernels of a stream never overlap) is unaffected.
 # IPDM_DEVICE_TURNS=1 makes ranks that share a card take turns: a rank computes only while it holds an exclusive file lock
 # and passes it on around every collective, so the rehearsal is bit-reproducible (tests/test_scripts_gpu.py).
 _TURN = {"fd": None, "held": False}

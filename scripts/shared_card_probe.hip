@@ -1,8 +1,10 @@
 // Diagnostic for ranks / streams that SHARE one MI355X (sharding.py): kernels launched on stream B ("victims": a
 // checksum of scalar fp32 VALU math, the same with v_pk_mul_f32 / v_pk_add_f32, and the library's bilinear resize, whose
 // compiler-generated code uses the packed instructions) are compared bit for bit with a quiet run while stream A runs an
-// "aggressor" (the library's convolution kernels, a synthetic MFMA chain).  Result on MI355X / ROCm 7.2
-// (profiles/r03_shared_card_probe.txt): the direct 3x3 split-operand kernels corrupt the packed-fp32 victims, nothing else does.
+// "aggressor" (the library's convolution kernels; synthetic kernels: a chain of f16 MFMAs on constant operands, and the same
+// chain fed by global loads / by ds_read_b128 / by both).  Result on MI355X / ROCm 7.2 (profiles/r03_shared_card_probe.txt):
+// the packed-fp32 victims are corrupted by the library's direct 3x3 split-operand kernels AND by the 30-line synthetic kernel
+// whose MFMA operands come from LDS reads -- the disturbance does not need this library; scalar-fp32 victims are never hit.
 //   hipcc --offload-arch=gfx950 -O2 -Iinclude scripts/shared_card_probe.hip -o _variants/shared_card_probe \
 //         -Linverseproblemwithdiffusionmodel_amd -lipdm -Wl,-rpath,'$ORIGIN/../inverseproblemwithdiffusionmodel_amd'
 #include <hip/hip_runtime.h>
@@ -78,6 +80,34 @@ __global__ __launch_bounds__(256, 2) void mfma_hog(float* sink, int iters) {
   if (s == 12345.678f) sink[0] = s;
 }
 
+// synthetic aggressor with the direct kernel's instruction mix: per step two 16-byte global loads (L2-resident weights), two
+// ds_read_b128 and three chained f16 MFMAs whose operands ARE the loaded values
+template <int NLOAD, int NDS>
+__global__ __launch_bounds__(256, 2) void mix_hog(const uint4* __restrict__ wbuf, float* sink, int iters) {
+  extern __shared__ __align__(16) uint4 mixl[];
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < 2048; i += 256) mixl[i] = make_uint4(0x3c003c00u + i, 0x3c003c00u, 0x38003800u, 0x34003400u);
+  __syncthreads();
+  f32x16 acc[4];
+  for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  uint4 a0 = wbuf[lane], a1 = wbuf[64 + lane], b0 = mixl[lane], b1 = mixl[64 + lane];
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+      if (NLOAD) { na0 = wbuf[((it * 4 + k) * 128 + lane) & 4095]; na1 = wbuf[((it * 4 + k) * 128 + 64 + lane) & 4095]; }
+      if (NDS == 1) { nb0 = mixl[((it + k) * 64 + lane) & 2047]; nb1 = mixl[((it + k) * 64 + 1024 + lane) & 2047]; }
+      acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, b0), acc[k], 0, 0, 0);
+      acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b1), acc[k], 0, 0, 0);
+      acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b0), acc[k], 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+  }
+  float sm = 0.f;
+  for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) sm += acc[k][r];
+  if (sm == 12345.678f) sink[0] = sm;
+}
+
 int main() {
   const int B = 48, C = 256, IH = 8;
   const long long n_in = (long long)B * C * IH * IH;
@@ -134,7 +164,8 @@ int main() {
   const char* vnames[] = {"v_mul/v_add f32", "v_pk_mul/v_pk_add f32", "ipdm_bilinear_f32 8->16"};
   const char* anames[] = {"none", "hx2 direct 3x3 8x8", "bx3 direct 3x3 8x8", "hx2 direct 1x1 8x8", "bx3 direct 1x1 8x8",
                           "hx2 direct 3x3 dil2 8x8", "bx3 direct 3x3 dil2 8x8", "hx2 direct 3x3 64x64", "bx3 direct 3x3 64x64",
-                          "hx2 winograd 64x64", "bx3 winograd 64x64", "fp32 mfma conv 3x3 8x8", "mfma chain 3"};
+                          "hx2 winograd 64x64", "bx3 winograd 64x64", "fp32 mfma conv 3x3 8x8", "mfma chain 3",
+                          "synthetic mfma + global loads", "synthetic mfma + ds_read_b128", "synthetic mfma + both"};
   auto run_victim = [&](int v, unsigned* out) {
     const int rounds = 64;
     if (v == 0) hipLaunchKernelGGL(victim<0>, dim3(NV / 256), dim3(256), 0, sb, vin, out, rounds);
@@ -147,7 +178,7 @@ int main() {
     const long long nchk = v == 2 ? nb_out : (long long)NV;
     run_victim(v, vref);
     CK(hipStreamSynchronize(sb));
-    for (int g = 0; g < 13; ++g) {
+    for (int g = 0; g < 16; ++g) {
       CK(hipMemsetAsync(cnt, 0, 4, sb));
       const int reps = 200;
       int arc = 0;
@@ -165,6 +196,9 @@ int main() {
           case 10: arc |= ipdm_conv2d_wino_bx3_f32(x2, u_bx, nullptr, nullptr, o2, nullptr, 0, B2, C2, C2, H2, H2, 1, 0, nullptr, sa); break;
           case 11: arc |= ipdm_conv2d_f32(cx, wt32, nullptr, nullptr, 0, nullptr, cout_, nullptr, 0, B, C, C, IH, IH, 3, 1, 0, sa); break;
           case 12: hipLaunchKernelGGL(mfma_hog<3>, dim3(512), dim3(256), 0, sa, sink, 130); break;
+          case 13: hipLaunchKernelGGL((mix_hog<1, 0>), dim3(512), dim3(256), 32768, sa, reinterpret_cast<const uint4*>(w), sink, 100); break;
+          case 14: hipLaunchKernelGGL((mix_hog<0, 1>), dim3(512), dim3(256), 32768, sa, reinterpret_cast<const uint4*>(w), sink, 100); break;
+          case 15: hipLaunchKernelGGL((mix_hog<1, 1>), dim3(512), dim3(256), 32768, sa, reinterpret_cast<const uint4*>(w), sink, 100); break;
           default: break;
         }
         run_victim(v, vout);
