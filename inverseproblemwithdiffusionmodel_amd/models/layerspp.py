@@ -54,17 +54,33 @@ def _skip(x, h, rescale):
 class _TembBias:
     """`h = Conv_0(.) ; h += Dense_0(act(temb))[:, :, None, None]` (reference models/layerspp.py:190-192, 252-254) as ONE bias row
     per image in the convolution's epilogue: rows = Dense_0(act(temb)) with the convolution's own bias added into the
-    Dense bias (cached; refreshed when either parameter changes)"""
+    Dense bias.  The [Cout] sum is cached under the PARAMETERS' own version counters (a `.data` view has a counter of its own that
+    never moves: `p.copy_()` -- load_state_dict, an optimiser step -- bumps `p._version` only); a write through `.data` (the
+    reference's EMA swap) bumps nothing, so the owning block also clears the cache in its load_state_dict hook and invalidate()"""
 
     def __init__(self):
         self._tag, self._sum = None, None
 
+    def clear(self):
+        self._tag, self._sum = None, None
+
     def rows(self, dense, conv, temb, code):
-        b_d, b_c = dense.bias.data, conv.bias.data
+        b_d, b_c = dense.bias, conv.bias
         tag = (b_d._version, b_d.data_ptr(), b_c._version, b_c.data_ptr())
         if tag != self._tag:
-            self._sum, self._tag = (b_d + b_c).contiguous(), tag
+            self._sum, self._tag = (b_d.data + b_c.data).contiguous(), tag
         return ops.linear(temb, dense.weight.data, self._sum, code)
+
+
+class _TembBiasOwner:
+    """for blocks holding `self._temb_bias`: the cached bias sum is dropped whenever the state dict is loaded, and on invalidate()"""
+
+    def invalidate(self):
+        self._temb_bias.clear()
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._temb_bias.clear()
+        return super()._load_from_state_dict(*args, **kwargs)
 
 
 class AttnBlockpp(nn.Module):
@@ -133,7 +149,7 @@ class Downsample(nn.Module):
         return self.Conv2d_0(x)
 
 
-class ResnetBlockDDPMpp(nn.Module):
+class ResnetBlockDDPMpp(_TembBiasOwner, nn.Module):
     """ResBlock adapted from DDPM (mirror of the reference's ``models/layerspp.py:166-209``): GroupNorm+act -> conv3x3
     -> + Dense(act(temb)) -> GroupNorm+act -> (dropout: identity when sampling) -> conv3x3, shortcut through NIN (or a
     3x3 convolution) when the channel count changes; same parameter names."""
@@ -176,7 +192,7 @@ class ResnetBlockDDPMpp(nn.Module):
         return _skip(x, h, self.skip_rescale)
 
 
-class ResnetBlockBigGANpp(nn.Module):
+class ResnetBlockBigGANpp(_TembBiasOwner, nn.Module):
     def __init__(self, act, in_ch, out_ch=None, temb_dim=None, up=False, down=False, dropout=0.1, fir=False,
                  fir_kernel=(1, 3, 3, 1), skip_rescale=True, init_scale=0.):
         super().__init__()

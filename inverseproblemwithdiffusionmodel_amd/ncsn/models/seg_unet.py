@@ -125,7 +125,6 @@ class UNet(nn.Module):
         g_d = ops.add(g_d, gcat[:, :c_skip].contiguous())                        # ... plus the skip half of the concat
         return down.backward_input(g_d, sd)
 
-    @torch.no_grad()
     def _check_size(self, x):
         """every stride-2 level halves the image and the transposed convolutions double it back: H and W must be multiples
         of 2^len(strides), otherwise the skip concatenations / the backward walk meet mismatched shapes mid-chain"""
@@ -133,6 +132,7 @@ class UNet(nn.Module):
         if x.dim() != 4 or x.shape[-2] % m or x.shape[-1] % m:
             raise ValueError(f"UNet: input {tuple(x.shape)}: H and W must be multiples of {m} (2^len(strides))")
 
+    @torch.no_grad()
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("UNet: expected GPU tensors (no CPU fallback in this build)")

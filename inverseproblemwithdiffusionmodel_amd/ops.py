@@ -44,8 +44,30 @@ def _inplace_operand(t, dtype, name):
     return t
 
 
+# One stream per device.  Two HSA queues on one card corrupt each other's packed-fp32 VALU results while certain MFMA kernels are
+# resident (profiles/r03_shared_card_probe.txt; sharding.py), and kernels of ONE stream never overlap -- so the library refuses
+# to be driven from a second eager stream of the same device.  Capture streams are exempt (torch.cuda.graph records on a side
+# stream that never executes; a graph replays on the stream that launches it).  IPDM_ALLOW_MULTI_STREAM=1 lifts the check.
+_STREAM_OF_DEVICE = {}
+
+
 def _stream():
-    return P(torch.cuda.current_stream().cuda_stream)
+    st = torch.cuda.current_stream()
+    h = st.cuda_stream
+    if _STREAM_OF_DEVICE.get(st.device_index, h) != h or st.device_index not in _STREAM_OF_DEVICE:
+        _note_stream(st.device_index, h)
+    return P(h)
+
+
+def _note_stream(dev, h):
+    if torch.cuda.is_current_stream_capturing():
+        return
+    first = _STREAM_OF_DEVICE.setdefault(dev, h)
+    if first != h and os.environ.get("IPDM_ALLOW_MULTI_STREAM", "0") != "1":
+        raise RuntimeError(
+            f"ipdm: kernels were launched on stream {first:#x} of cuda:{dev} and now on stream {h:#x}: this library runs on ONE "
+            "stream per device (two queues on one MI355X silently corrupt packed-fp32 results, "
+            "profiles/r03_shared_card_probe.txt). Use one stream, or set IPDM_ALLOW_MULTI_STREAM=1 to take the risk.")
 
 
 def _c64_as_f32(t):

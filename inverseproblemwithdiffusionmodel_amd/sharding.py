@@ -67,9 +67,28 @@ def init_distributed():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if world > 1 and os.environ.get("IPDM_DEVICE_TURNS", "0") == "1":
+    turns = os.environ.get("IPDM_DEVICE_TURNS", "0") == "1"
+    if world > 1:
+        _refuse_shared_cards(world, rank, dev_index, turns)
+    if world > 1 and turns:
         start_turns()
     return world, rank, device
+
+
+def _refuse_shared_cards(world, rank, dev_index, turns):
+    """two ranks on one card WITHOUT the turn-taking give silently wrong bits (module header): raise on every rank instead.
+    (host name, device index) of all ranks are exchanged once through the process group just created."""
+    import socket
+    mine = (socket.gethostname(), int(dev_index))
+    seats = [None] * world
+    dist.all_gather_object(seats, mine)
+    shared = sorted({s for s in seats if seats.count(s) > 1})
+    if shared and not turns:
+        raise RuntimeError(
+            f"ipdm sharding: ranks {[r for r, s in enumerate(seats) if s in shared]} resolve to the same card(s) {shared} "
+            "(LOCAL_RANK collision or IPDM_BENCH_DEVICE). Two processes computing on one MI355X at once corrupt each other's "
+            "packed-fp32 results (profiles/r03_shared_card_probe.txt). Give every rank its own GPU, or -- to rehearse on one card "
+            "-- set IPDM_DEVICE_TURNS=1 so that the ranks take turns.")
 
 
 def start_turns():
@@ -81,16 +100,31 @@ def start_turns():
 
 
 def gather_samples(local, total, world, rank):
-    """every rank's block of samples -> the (total, ...) tensor in global sample order on every rank: one all-reduce(SUM)
-    of a zero-filled buffer in which a rank fills only its own rows (adding zeros is exact, so the result carries the
-    ranks' bits unchanged whatever the backend's reduction order)"""
+    """every rank's block of samples -> the (total, ...) tensor in global sample order on every rank, bit for bit.
+    RCCL: ONE all_gather_into_tensor of equal blocks (every rank pads its block to the largest shard: 105 -> 14 rows) -- each
+    byte crosses a link once; config 4's (32, 24, 1, 128, 128) complex64 = 100 MB moves as 100 MB, not as an 8x larger
+    all-reduce.  gloo (the CPU / one-card rehearsals; no all_gather_into_tensor for every build): one all-reduce(SUM) of a
+    zero-filled buffer in which a rank fills only its own rows (adding zeros is exact, so the bits survive any reduction order).
+    IPDM_GATHER=allgather|allreduce overrides the choice."""
     if world == 1:
         return local
+    sizes = shard_sizes(total, world)
     lo, hi = shard_range(total, world, rank)
     real = torch.view_as_real(local) if local.is_complex() else local
-    buf = torch.zeros((total,) + tuple(real.shape[1:]), dtype=real.dtype, device=real.device)
-    buf[lo:hi] = real[: hi - lo]
-    all_reduce(buf)
+    mode = os.environ.get("IPDM_GATHER") or ("allgather" if dist.get_backend() == "nccl" else "allreduce")
+    if mode == "allgather":
+        blk = max(sizes)
+        mine = torch.zeros((blk,) + tuple(real.shape[1:]), dtype=real.dtype, device=real.device)
+        mine[: hi - lo] = real[: hi - lo]
+        gathered = torch.empty((world * blk,) + tuple(real.shape[1:]), dtype=real.dtype, device=real.device)
+        _pass_turn()
+        dist.all_gather_into_tensor(gathered, mine)
+        _take_turn()
+        buf = torch.cat([gathered[r * blk: r * blk + n] for r, n in enumerate(sizes)], dim=0)
+    else:
+        buf = torch.zeros((total,) + tuple(real.shape[1:]), dtype=real.dtype, device=real.device)
+        buf[lo:hi] = real[: hi - lo]
+        all_reduce(buf)
     return torch.view_as_complex(buf) if local.is_complex() else buf
 
 

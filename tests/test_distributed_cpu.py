@@ -91,3 +91,52 @@ def test_shared_card_turns_world2(tmp_path):
     assert len(lines) == 12
     for a, b in zip(lines[0::2], lines[1::2]):          # sections never interleave: every enter is followed by its own leave
         assert a.startswith("enter") and b == a.replace("enter", "leave"), lines
+
+
+def _gather_worker(rank, world, port, total, mode, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["IPDM_GATHER"] = mode
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from inverseproblemwithdiffusionmodel_amd import sharding
+    a, b = sharding.shard_range(total, world, rank)
+    full = sharding.gather_samples(_samples(total)[a:b].clone(), total, world, rank)
+    torch.save(full, os.path.join(out_dir, f"full_{mode}_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_samples_world2_is_bit_preserving(tmp_path):
+    """both forms of gather_samples (padded equal blocks through all_gather_into_tensor -- the RCCL form -- and the zero-buffer
+    all-reduce kept for gloo) return every rank's rows in global order, bit for bit, on every rank; uneven split 4 + 3"""
+    total = 7
+    ref = _samples(total)
+    for mode in ("allgather", "allreduce"):
+        mp.spawn(_gather_worker, args=(2, _free_port(), total, mode, str(tmp_path)), nprocs=2, join=True)
+        for rank in range(2):
+            got = torch.load(os.path.join(tmp_path, f"full_{mode}_{rank}.pt"))
+            assert got.dtype == ref.dtype and torch.equal(torch.view_as_real(got), torch.view_as_real(ref)), (mode, rank)
+
+
+def _seat_worker(rank, world, port, dev_of_rank, turns, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from inverseproblemwithdiffusionmodel_amd import sharding
+    try:
+        sharding._refuse_shared_cards(world, rank, dev_of_rank[rank], turns)
+        verdict = "ok"
+    except RuntimeError as e:
+        verdict = "refused" if "IPDM_DEVICE_TURNS" in str(e) else f"other: {e}"
+    with open(os.path.join(out_dir, f"seat_{rank}.txt"), "w") as f:
+        f.write(verdict)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_card_are_refused_without_turns(tmp_path):
+    """init_distributed's seat check: two ranks resolving to one device index raise on EVERY rank unless they take turns"""
+    for devs, turns, want in (((0, 0), False, "refused"), ((0, 0), True, "ok"), ((0, 1), False, "ok")):
+        mp.spawn(_seat_worker, args=(2, _free_port(), devs, turns, str(tmp_path)), nprocs=2, join=True)
+        for rank in range(2):
+            assert open(os.path.join(tmp_path, f"seat_{rank}.txt")).read() == want, (devs, turns, rank)
