@@ -34,8 +34,16 @@ extern "C" {
 #define IPDM_ACT_LRELU02 3
 #define IPDM_ACT_SWISH 4
 
+/* "maxima vectors": per-image max |x| of an activation tensor (or an upper bound of it), what the f16x2 convolutions take as
+ * `in_amax` (dynamic range) and what producers hand over (`out_amax`, `act_amax`, `amax_out`, `amax_bound` below).  Layout:
+ * [B][IPDM_AMAX_SLOT] floats, 8 ways per image at a stride of 16 floats (one 64-byte line each: memory-side atomics serialise per
+ * line); the value of an image is the max over its ways.  Atomic producers need the whole vector ZEROED by the caller;
+ * ipdm_absmax_f32 and the coefficient kernels write every way themselves. */
+#define IPDM_AMAX_WAYS 8
+#define IPDM_AMAX_SLOT 128
+
 /* library identification: returns IPDM_ABI_VERSION, writes the gfx arch string the kernels were built for */
-#define IPDM_ABI_VERSION 3
+#define IPDM_ABI_VERSION 4
 int ipdm_abi_version(void);
 const char* ipdm_build_arch(void);
 
@@ -195,7 +203,11 @@ int ipdm_philox_block_host(uint64_t seed, int64_t sample, int64_t step_id, int p
  *   InstanceNorm2dPlus(x)[b,c,:,:] = (x - mu) * scale + shift
  * gamma/alpha/beta are the module's parameters ([C] each; beta may be NULL). Two launches. */
 int ipdm_instnorm_plus_coef_f32(const float* x, const float* alpha, const float* gamma, const float* beta,
-                                float* coef, int B, int C, int HW, void* stream);
+                                float* coef, int B, int C, int HW,
+                                float* amax_bound /* NULL, or a maxima vector: an upper bound of max |normalised value| per image, from the
+                                                     coefficients alone (|x - mu| * rstd < sqrt(HW)) -- the in_amax of the f16x2
+                                                     convolution that reads the normalised tensor, at no pass over it */,
+                                void* stream);
 /* y = act((x - mu) * scale + shift) with coef from above; x may equal y */
 int ipdm_affine_act_f32(const float* x, const float* coef, float* y, int B, int C, int HW, int act, void* stream);
 /* y = act(x) elementwise */
@@ -223,11 +235,14 @@ int ipdm_maxpool5_f32(const float* x, float* y, int planes, int H, int W, void* 
 int ipdm_meanpool2_f32(const float* x, float* y, int planes, int H, int W, void* stream);
 /* bilinear resize, align_corners=True: out = act(resize(x) [+ out]); accumulate != 0 adds the previous out */
 int ipdm_bilinear_f32(const float* x, float* out, int planes, int in_h, int in_w, int out_h, int out_w,
-                      int accumulate, int act /* applied to the value written */, void* stream);
+                      int accumulate, int act /* applied to the value written */,
+                      int planes_per_image, float* amax_out /* NULL, or a maxima vector ([planes / planes_per_image] images) zeroed by the
+                                                               caller: per-image max |value written| (atomic max), see ipdm_conv_ext_t */,
+                      void* stream);
 /* trilinear resize, align_corners=True, of [planes][D][H][W] volumes (the 3-D MSF block's F.interpolate,
  * ncsn/models/layers3d.py:185,214); same accumulate / act convention */
 int ipdm_trilinear_f32(const float* x, float* out, int planes, int in_d, int in_h, int in_w, int out_d, int out_h,
-                       int out_w, int accumulate, int act, void* stream);
+                       int out_w, int accumulate, int act, int planes_per_image, float* amax_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * NCSN++ / predictor-corrector extras (reference: torch.nn.GroupNorm(eps 1e-6) in models/layerspp.py:66,219
@@ -313,16 +328,21 @@ int ipdm_temporal_taps_f32(const float* x, float* out, int planes, int S, int T_
 
 /* Optional extras of the split-operand convolution calls below (`ext` may be NULL = all defaults).  A HOST struct, read when
  * the call is made (its device pointer member is dereferenced by the kernel):
- *   in_amax       f16x2 calls only: per-image max |x| [B] (ipdm_absmax_f32) -> dynamic range, see the f16x2 note; NULL = static
+ *   in_amax       f16x2 calls only: maxima vector of the input (ipdm_absmax_f32, or a producer's out_amax / act_amax / amax_out /
+ *                 amax_bound) -> dynamic range, see the f16x2 note; NULL = static
  *   bias_bstride  bias index = image * bias_bstride + channel: Cout gives one bias ROW PER IMAGE (the reference's
  *                 `h += Dense_0(act(temb))[:, :, None, None]` after a convolution, models/layerspp.py:252-254, folded into the
  *                 epilogue); 0 = the usual per-channel bias
+ *   out_amax / act_amax   see the struct
  *   out_scale     result = (conv + bias + residual) * out_scale -- the skip_rescale of the score_sde blocks,
  *                 (x + h) / sqrt(2) (models/layerspp.py:271-274), folded into the epilogue; 0 is read as 1 */
 typedef struct {
   const float* in_amax;
   int bias_bstride;
   float out_scale;
+  float* out_amax;   /* maxima vector ZEROED by the caller, or NULL: per-image max |out| of what the call stores, accumulated with  */
+  float* act_amax;   /* atomic max (exact, order-independent) -- likewise for out_act.  What the NEXT f16x2 convolution takes as   */
+                     /* in_amax: the dynamic range then costs no pass over the tensor (the reference has no counterpart: fp32)      */
 } ipdm_conv_ext_t;
 
 /* ---- fp32 convolution on the bf16 matrix cores ("bf16x3": exact three-way operand split, six
@@ -392,13 +412,15 @@ int ipdm_conv2d_wino_bx3_stats_f32(const float* x, const void* U, const float* b
  * shapes) under a RANGE contract: weights are scaled per output channel by a power of two at pack time (the inverse scale
  * rides in the blob); activations must satisfy |x| < 65504 (the Winograd calls pre-scale their input transform to keep that bound) -- beyond that the result
  * is NaN / inf (never a wrong finite number); the bx3 calls keep the whole fp32 exponent range.  DYNAMIC RANGE: `ext->in_amax`
- * (NULL = the static contract above) is the per-image max |x| [B] of the input as ipdm_absmax_f32 writes it; the kernels
+ * (NULL = the static contract above) is the maxima vector of the input (ipdm_absmax_f32 measures one; producers hand theirs
+ * over, see ipdm_conv_ext_t); the kernels
  * then scale every image by the power of two that puts its maximum in [2^14, 2^15) and undo it in the epilogue (both exact), so
  * ANY fp32 input is in range and values down to 2^-17 of an image's maximum keep all 22 bits.  (Ignored -- pass NULL -- when the
  * call fuses an input normalisation / activation: the normalised values are what is split.)  Same other arguments, semantics
  * and replaced reference interface (torch.nn.Conv2d / Conv3d inside ncsn/models/layers.py:28-60) as their bx3 twins; the
  * shape rules (ipdm_conv_bx3_splitk, ipdm_conv2d_wino_bx3_supported / _splitk / _stats_partials) are shared. */
-int ipdm_absmax_f32(const float* x, float* amax /* [n_images] */, int n_images, int64_t per_image, void* stream);
+int ipdm_absmax_f32(const float* x, float* amax /* maxima vector [n_images][IPDM_AMAX_SLOT], zeroed by the call */, int n_images,
+                    int64_t per_image, void* stream);
 int64_t ipdm_conv_hx2_weight_bytes(int Cout, int Cin, int k);
 int ipdm_conv_hx2_pack_weight(const float* w /* [Cout][Cin][k][k] or [Cout][Cin][3][3][3] */, void* packed, int Cout,
                               int Cin, int k, void* stream);
@@ -425,6 +447,7 @@ int ipdm_conv2d_wino_hx2_stats_f32(const float* x, const void* U, const float* b
                                    int pool2, float* stats, const ipdm_conv_ext_t* ext, void* stream);
 int ipdm_instnorm_plus_coef_partials_f32(const float* partials, int P, const float* alpha, const float* gamma,
                                          const float* beta /* may be NULL */, float* coef /* [B][C][3] */, int B, int C,
+                                         int HW /* elements per plane: only the bound needs it */, float* amax_bound /* as above */,
                                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -16,7 +16,8 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 class ConvExt(ctypes.Structure):
     """ipdm_conv_ext_t (include/ipdm.h): optional extras of the split-operand convolution calls"""
-    _fields_ = [("in_amax", c_void_p), ("bias_bstride", c_int), ("out_scale", c_float)]
+    _fields_ = [("in_amax", c_void_p), ("bias_bstride", c_int), ("out_scale", c_float), ("out_amax", c_void_p),
+                ("act_amax", c_void_p)]
 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -49,7 +50,7 @@ SIGNATURES = {
     "ipdm_langevin_step_f32": [P, P, P, c_float, c_float, c_uint64, c_int64, c_int64, P, c_int64, c_int64, P],
     "ipdm_philox_normal_f32": [P, c_uint64, c_int64, c_int64, c_int, c_int64, c_int64, P],
     "ipdm_philox_block_host": [c_uint64, c_int64, c_int64, c_int, ctypes.c_uint32, P],
-    "ipdm_instnorm_plus_coef_f32": [P, P, P, P, P, c_int, c_int, c_int, P],
+    "ipdm_instnorm_plus_coef_f32": [P, P, P, P, P, c_int, c_int, c_int, P, P],
     "ipdm_affine_act_f32": [P, P, P, c_int, c_int, c_int, c_int, P],
     "ipdm_act_f32": [P, P, c_int64, c_int, P],
     "ipdm_scale_shift_f32": [P, P, c_int64, c_float, c_float, P],
@@ -57,10 +58,10 @@ SIGNATURES = {
     "ipdm_div_sigma_f32": [P, P, P, P, c_int, c_int64, P],
     "ipdm_maxpool5_f32": [P, P, c_int, c_int, c_int, P],
     "ipdm_meanpool2_f32": [P, P, c_int, c_int, c_int, P],
-    "ipdm_bilinear_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "ipdm_bilinear_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "ipdm_conv3x3_thin_supported": [c_int, c_int, c_int, c_int],
     "ipdm_conv3x3_thin_f32": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
-    "ipdm_trilinear_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "ipdm_trilinear_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "ipdm_groupnorm_coef_f32": [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P, P],
     "ipdm_groupnorm_coef_cat_f32": [P, c_int, P, c_int, P, P, P, c_int, c_int, c_int, c_float, P, P],
     "ipdm_affine_act_cat_f32": [P, c_int, P, c_int, P, P, c_int, c_int, c_int, P],
@@ -104,7 +105,7 @@ SIGNATURES = {
     "ipdm_conv2d_wino_hx2_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "ipdm_conv2d_wino_hx2_splitk_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P],
     "ipdm_conv2d_wino_hx2_stats_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P],
-    "ipdm_instnorm_plus_coef_partials_f32": [P, c_int, P, P, P, P, c_int, c_int, P],
+    "ipdm_instnorm_plus_coef_partials_f32": [P, c_int, P, P, P, P, c_int, c_int, c_int, P, P],
     "ipdm_zero_insert2_f32": [P, P, c_int, c_int, c_int, P],
     "ipdm_subsample2_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "ipdm_in_prelu_fwd_f32": [P, P, P, P, P, c_int, c_int, c_float, P],

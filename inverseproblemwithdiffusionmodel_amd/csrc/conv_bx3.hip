@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
   [[maybe_unused]] float hx_in = 1.f, hx_out = 1.f;
   [[maybe_unused]] const bool hx_dyn = HX && a.in_amax != nullptr;
   if constexpr (HX) {
-    if (hx_dyn) hx_dynamic_scale(a.in_amax[b], hx_in, hx_out);
+    if (hx_dyn) hx_dynamic_scale(ipdm_amax_read_v(a.in_amax + (size_t)b * IPDM_AMAX_SLOT), hx_in, hx_out);
   }
   float preg[C::ITEMS][8];
   auto chunk_kz_c0 = [&](int ch, int& kz, int& c0) {
@@ -398,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
       if constexpr (HX) asm volatile("" : "+v"(sv[m][r]));
     }
   load_res(std::integral_constant<int, 0>{});
+  float amx_o = 0.f, amx_a = 0.f;                 // max |stored value| of this thread (a.amax_out / a.amax_act; one image per workgroup)
   static_for<NBATCH>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
     constexpr int n = q / NCT, m = q % NCT;
@@ -429,12 +430,22 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
           if (has_bias) v += bv[m][r];
           if (has_res) v += rv[q & 1][r];
           v *= a.out_scale;
+          amx_o = fmaxf(amx_o, fabsf(v));
           if (a.out) a.out[o] = v;
-          if (a.out_act) a.out_act[o] = a.act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, a.act_out);
+          if (a.out_act) {
+            const float e = a.act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, a.act_out);
+            amx_a = fmaxf(amx_a, fabsf(e));
+            a.out_act[o] = e;
+          }
         }
       }
     }
   });
+  if (finish) {
+    const int way = (int)(blockIdx.x & 1) * 4 + wave;          // (four waves per workgroup: neighbours take the other four ways)
+    if (a.amax_out) ipdm_amax_commit(amx_o, a.amax_out + (size_t)b * IPDM_AMAX_SLOT, way);
+    if (a.amax_act) ipdm_amax_commit(amx_a, a.amax_act + (size_t)b * IPDM_AMAX_SLOT, way);
+  }
   if (a.dbg) {                                   // tuning aid (ipdm_debug_set_stamp_buffer); NULL in production
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long t3 = __builtin_amdgcn_s_memtime();
@@ -516,16 +527,30 @@ __global__ __launch_bounds__(256) void bx3_splitk_reduce_kernel(const float* __r
                                                                 const float* __restrict__ bias,
                                                                 const float* __restrict__ residual, float* out,
                                                                 float* out_act, int act_out, int Cout, int64_t plane,
-                                                                int64_t total, int bias_bstride, float out_scale) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+                                                                int64_t total, int bias_bstride, float out_scale,
+                                                                float* amax_out, float* amax_act) {
+  // grid = (blocks per image, images) when the maxima are wanted (a workgroup then stays inside one image), else 1-D grid-stride
+  const int64_t per_image = plane * Cout;
+  const bool by_image = gridDim.y > 1 || amax_out || amax_act;      // (launchers: B <= 65535 whenever the maxima are wanted)
+  const int64_t lo = by_image ? (int64_t)blockIdx.y * per_image : 0, hi = by_image ? lo + per_image : total;
+  float amx_o = 0.f, amx_a = 0.f;
+  for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)gridDim.x * 256) {
     float v = partial[i];
     for (int s = 1; s < ksplit; ++s) v += partial[(size_t)s * total + i];
-    if (bias) v += bias[(i / (plane * Cout)) * bias_bstride + (i / plane) % Cout];
+    if (bias) v += bias[(i / per_image) * bias_bstride + (i / plane) % Cout];
     if (residual) v += residual[i];
     v *= out_scale;
+    amx_o = fmaxf(amx_o, fabsf(v));
     if (out) out[i] = v;
-    if (out_act) out_act[i] = act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, act_out);
+    if (out_act) {
+      const float e = act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, act_out);
+      amx_a = fmaxf(amx_a, fabsf(e));
+      out_act[i] = e;
+    }
   }
+  __shared__ float red[2][4];
+  if (amax_out) ipdm_amax_commit_block(amx_o, amax_out + (size_t)blockIdx.y * IPDM_AMAX_SLOT, (int)blockIdx.x, red[0]);
+  if (amax_act) ipdm_amax_commit_block(amx_a, amax_act + (size_t)blockIdx.y * IPDM_AMAX_SLOT, (int)blockIdx.x, red[1]);
 }
 
 // Split-K pays only when the tiles alone leave most of the chip idle (small images at small batch).  It is offered
@@ -694,6 +719,7 @@ static int conv_bx3_splitk_entry(const float* x, const void* wq, const float* bi
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0 && (k == 1 || k == 3) && dilation >= 1);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && wq && work && ksplit > 1 && (out || out_act) && x != out && x != out_act);
+  IPDM_REQUIRE(B <= 65535 || !ext || (!ext->out_amax && !ext->act_amax));
   if (k == 3 && dilation > 4) return IPDM_EUNSUPPORTED;
   ConvArgs a;
   a.x = x; a.wt = (const float*)wq; a.bias = nullptr; a.coef = coef; a.residual = nullptr; a.out = nullptr; a.out_act = nullptr;
@@ -705,12 +731,16 @@ static int conv_bx3_splitk_entry(const float* x, const void* wq, const float* bi
   conv_apply_ext(a, ext, hx);
   const float out_scale = a.out_scale;
   a.out_scale = 1.f;                            // the parts are raw partial sums; the reduce pass applies bias / residual / scale
+  float* const amax_out = a.amax_out;
+  float* const amax_act = a.amax_act;
+  a.amax_out = a.amax_act = nullptr;            //   ... and takes the maxima
   int rc = conv_bx3_dispatch(a, k, ipdm_stream(stream));
   a.out_scale = out_scale;
   if (rc != IPDM_OK) return rc;
   const int64_t plane = (int64_t)D * H * W, total = (int64_t)B * Cout * plane;
-  hipLaunchKernelGGL(bx3_splitk_reduce_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, ipdm_stream(stream), work, ksplit,
-                     bias, residual, out, out_act, act_out, Cout, (long long)plane, (long long)total, a.bias_bstride, a.out_scale);
+  hipLaunchKernelGGL(bx3_splitk_reduce_kernel, splitk_reduce_grid(B, Cout * plane, amax_out || amax_act), dim3(256), 0,
+                     ipdm_stream(stream), work, ksplit, bias, residual, out, out_act, act_out, Cout, (long long)plane,
+                     (long long)total, a.bias_bstride, a.out_scale, amax_out, amax_act);
   return ipdm_launch_status();
 }
 

@@ -124,8 +124,10 @@ struct ConvArgs {
   int bias_bstride = 0;      // split-operand kernels: bias index = image * bias_bstride + channel (Cout: one bias row per image, e.g.
                              //   conv bias + the time-embedding shift of a score_sde block; 0: the usual per-channel bias)
   float out_scale = 1.f;     //   ... and result = (conv + bias + residual) * out_scale (score_sde skip_rescale: 1 / sqrt 2)
-  const float* in_amax = nullptr;   // f16x2 only: per-image max |x| [B] (ipdm_absmax_f32) -> per-image power-of-two input scale
-                                    //   (hx_dynamic_scale); NULL: static range contract |x| < 65504
+  const float* in_amax = nullptr;   // f16x2 only: maxima vector of the input ([B][IPDM_AMAX_SLOT], ipdm.h) -> per-image power-of-two
+                                    //   input scale (hx_dynamic_scale(ipdm_amax_read(.))); NULL: static range contract |x| < 65504
+  float* amax_out = nullptr; // split-operand kernels: maxima vectors ([B][IPDM_AMAX_SLOT], zeroed by the caller) of out / out_act: max
+  float* amax_act = nullptr; //   |stored value| per image, one atomic max per wave (ipdm_common.h) -- the NEXT convolution's in_amax
   int hx = 0;                // conv_bx3 / conv_wino_bx3: 1 = the weights are an f16x2 blob (two fp16 pieces + per-channel inverse
                              //   scales), run the three-MFMA fp16 instantiation
   float* stats = nullptr;    // conv_wino_bx3 wide kernel (16 x 4 tile block, 16-byte DMA) only: per-plane statistics of
@@ -139,13 +141,24 @@ __global__ __launch_bounds__(256) void bx3_splitk_reduce_kernel(const float* __r
                                                                 const float* __restrict__ bias,
                                                                 const float* __restrict__ residual, float* out,
                                                                 float* out_act, int act_out, int Cout, int64_t plane,
-                                                                int64_t total, int bias_bstride, float out_scale);
+                                                                int64_t total, int bias_bstride, float out_scale,
+                                                                float* amax_out, float* amax_act);
+
+// its grid: 1-D grid-stride, or (blocks per image, images) when per-image maxima are wanted
+inline dim3 splitk_reduce_grid(int B, int64_t per_image, bool by_image) {
+  if (!by_image || B > 65535) return dim3((unsigned)ipdm_ew_grid((int64_t)B * per_image, 256));
+  int64_t bx = (per_image + 255) / 256, cap = (2048 + B - 1) / B;
+  bx = bx < 1 ? 1 : (bx > cap ? cap : bx);
+  return dim3((unsigned)bx, (unsigned)B);
+}
 
 // optional extras of the split-operand entry points (include/ipdm.h: ipdm_conv_ext_t) -> ConvArgs
 inline void conv_apply_ext(ConvArgs& a, const ipdm_conv_ext_t* ext, int hx) {
   a.in_amax = hx && ext ? ext->in_amax : nullptr;
   a.bias_bstride = ext ? ext->bias_bstride : 0;
   a.out_scale = ext && ext->out_scale != 0.f ? ext->out_scale : 1.f;
+  a.amax_out = ext ? ext->out_amax : nullptr;
+  a.amax_act = ext ? ext->act_amax : nullptr;
 }
 
 // NCT x NPT MFMA tiles per wave, WCO x WPX waves (WCO*WPX == 4), PW = pixel-tile width (16 or 32),

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
   if constexpr (HX) {
     if (a.in_amax) {
       float sd, si;
-      hx_dynamic_scale(a.in_amax[b], sd, si);
+      hx_dynamic_scale(ipdm_amax_read_v(a.in_amax + (size_t)b * IPDM_AMAX_SLOT), sd, si);
       hx_in = HX_WINO_PRESCALE * sd;
       hx_out = si;
     }
@@ -476,6 +476,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
   const float* const scale_p = HX ? reinterpret_cast<const float*>(wq + 16 * pos_stride) : a.wt;   // f16x2: inverse scales
   float bv[2][4], sv[2][4];
   float2 rv[2][4][2];
+  float amx_o = 0.f, amx_a = 0.f;                             // max |stored value| of this thread (a.amax_out / a.amax_act)
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -541,20 +542,25 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
           }
           y0v *= a.out_scale;
           y1v *= a.out_scale;
+          amx_o = fmaxf(amx_o, fmaxf(fabsf(y0v), fabsf(y1v)));
           if constexpr (SMALL) {
             if (a.out) {
               a.out[o] = y0v;
               a.out[o + d] = y1v;
             }
             if (a.out_act) {
-              a.out_act[o] = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
-              a.out_act[o + d] = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
+              const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
+              const float e1 = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
+              amx_a = fmaxf(amx_a, fmaxf(fabsf(e0), fabsf(e1)));
+              a.out_act[o] = e0;
+              a.out_act[o + d] = e1;
             }
           } else {
             if (a.out) *reinterpret_cast<float2*>(a.out + o) = make_float2(y0v, y1v);
             if (a.out_act) {
               const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
               const float e1 = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
+              amx_a = fmaxf(amx_a, fmaxf(fabsf(e0), fabsf(e1)));
               *reinterpret_cast<float2*>(a.out_act + o) = make_float2(e0, e1);
             }
           }
@@ -562,6 +568,8 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
       }
     }
   }
+  if (a.amax_out) ipdm_amax_commit(amx_o, a.amax_out + (size_t)b * IPDM_AMAX_SLOT, wave);
+  if (a.amax_act) ipdm_amax_commit(amx_a, a.amax_act + (size_t)b * IPDM_AMAX_SLOT, wave);
   if (a.dbg) {
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long t3 = __builtin_amdgcn_s_memtime();
@@ -651,8 +659,18 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   const int q = total_tiles / 8, r8 = total_tiles % 8;
   const int x_start = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
   const int x_end = x_start + q + (xcd < r8 ? 1 : 0);
-  int tile = x_start + slot;
-  if (tile >= x_end) return;                                  // uniform: whole workgroup
+  // -DIPDM_WBX3_RUNS (tuning build): every workgroup walks a CONTIGUOUS run of the XCD's range (it then stays inside one or two images: fewer maxima
+  // commits and scale reloads) instead of striding through it with the XCD's other workgroups
+#ifdef IPDM_WBX3_RUNS
+  constexpr bool RUNS = true;
+#else
+  constexpr bool RUNS = false;
+#endif
+  const int per_wg = (x_end - x_start + S - 1) / S;
+  const int t_step = RUNS ? 1 : S;
+  const int t_end = RUNS ? (x_start + (slot + 1) * per_wg < x_end ? x_start + (slot + 1) * per_wg : x_end) : x_end;
+  int tile = RUNS ? x_start + slot * per_wg : x_start + slot;
+  if (tile >= t_end) return;                                  // uniform: whole workgroup
 
   struct Geo { int b, y0, x0, co_tile, c0, ks; };               // c0: first chunk of this workgroup's K range (KSP)
   auto geo_of = [&](int L) {
@@ -853,7 +871,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     if constexpr (HX) {
       if (a.in_amax) {
         float sd, si;
-        hx_dynamic_scale(a.in_amax[b], sd, si);
+        hx_dynamic_scale(ipdm_amax_read(a.in_amax + (size_t)b * IPDM_AMAX_SLOT), sd, si);
         s_in = HX_WINO_PRESCALE * sd;
         s_out = si;
       }
@@ -943,6 +961,15 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
   if (a.dbg) t1 = __builtin_amdgcn_s_memtime();
 
   int g = 0;                                                  // chunks done so far: stage parity
+  // pending maxima of the image whose tile passes this workgroup is in (see the epilogue)
+  [[maybe_unused]] int pend_b = cur_g.b;
+  [[maybe_unused]] unsigned pend_o = 0u, pend_a = 0u;
+  [[maybe_unused]] auto flush_amax = [&]() {
+    if (lane == 0) {
+      if (a.amax_out) ipdm_amax_atomic(a.amax_out + (size_t)pend_b * IPDM_AMAX_SLOT, wave, __builtin_bit_cast(float, pend_o));
+      if (a.amax_act) ipdm_amax_atomic(a.amax_act + (size_t)pend_b * IPDM_AMAX_SLOT, wave, __builtin_bit_cast(float, pend_a));
+    }
+  };
 #ifdef IPDM_WBX3_TRACE
   unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // step timeline of chunk 2 of the second tile (diagnostic build)
 #define IPDM_TR(k) if (a.dbg && trace_now) tr[k] = __builtin_amdgcn_s_memtime()
@@ -957,8 +984,8 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
 #define IPDM_TE(k)
 #endif
   while (true) {
-    const int next_tile = tile + S;
-    const bool has_next = next_tile < x_end;
+    const int next_tile = tile + t_step;
+    const bool has_next = next_tile < t_end;
     const Geo next_g = geo_of(has_next ? next_tile : tile);
     for (int ch = 0; ch < n_chunks; ++ch, ++g) {
 #ifdef IPDM_WBX3_TRACE
@@ -976,7 +1003,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       const int a_cot = a_next ? next_g.co_tile : cur_g.co_tile;
       if constexpr (HX) {
         [[maybe_unused]] float unused_out;
-        if (a_next) hx_scales_of(next_g.b, hx_in, unused_out);    // this chunk stages chunk 0 of the NEXT tile (its image's scale)
+        if (a_next && next_g.b != cur_g.b) hx_scales_of(next_g.b, hx_in, unused_out);   // this chunk stages chunk 0 of the NEXT tile (its image's scale)
       }
       if constexpr (WPRIV) {
         // this wave's DMA of chunk c+1 (issued a chunk ago) and the fragments of position p0 have landed: fragments of position
@@ -1237,7 +1264,19 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
         }
       }
     };
+    // maxima of what the PREVIOUS tile passes stored (wave-uniform, kept in scalar registers across the chunk loop) go out now,
+    // when the image changes: the atomics then complete under this epilogue's own stores.  Issued at the END of a tile pass they
+    // sat in front of the next chunk's fragment loads in the in-order vmcnt queue, and 256 waves per image-line made each take
+    // microseconds (ipdm_common.h).
+    if constexpr (!KSP) {
+      if (cur_g.b != pend_b) {
+        flush_amax();
+        pend_b = cur_g.b;
+        pend_o = pend_a = 0u;
+      }
+    }
     if constexpr (AHEAD) prefetch(std::integral_constant<int, 0>{});
+    [[maybe_unused]] float amx_o = 0.f, amx_a = 0.f;            // max |stored value| of this thread over the tile pass
     static_for<4>([&](auto rc) {
       constexpr int rnd = decltype(rc)::value;
       constexpr int c = rnd >> 1, tg = rnd & 1, bf = AHEAD ? rnd & 1 : 0;
@@ -1299,8 +1338,13 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
             if (has_res) v += resv[bf][i][0].x;
             v *= a.out_scale;
             if constexpr (STATS) sv[i][0] = v;
+            if constexpr (!KSP) amx_o = fmaxf(amx_o, fabsf(v));
             if (a.out) *reinterpret_cast<float*>(out_b + ob) = v;
-            if (a.out_act) *reinterpret_cast<float*>(act_b + ob) = a.act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, a.act_out);
+            if (a.out_act) {
+              const float e = a.act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, a.act_out);
+              if constexpr (!KSP) amx_a = fmaxf(amx_a, fabsf(e));
+              *reinterpret_cast<float*>(act_b + ob) = e;
+            }
           } else {
 #pragma unroll
           for (int ii = 0; ii < 2; ++ii) {
@@ -1326,6 +1370,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
               sv[i][2 * ii] = y0v;
               sv[i][2 * ii + 1] = y1v;
             }
+            if constexpr (!KSP) amx_o = fmaxf(amx_o, fmaxf(fabsf(y0v), fabsf(y1v)));
             if constexpr (POLY) {
               if (a.out) {
                 a.out[o] = y0v;
@@ -1339,6 +1384,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
             if (a.out_act) {
               const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
               const float e1 = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
+              if constexpr (!KSP) amx_a = fmaxf(amx_a, fmaxf(fabsf(e0), fabsf(e1)));
               if constexpr (POLY) {
                 a.out_act[o] = e0;
                 a.out_act[o + pd] = e1;
@@ -1394,15 +1440,24 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       __syncthreads();                                        // M is rewritten by the next round / the next tile's V
       IPDM_TE(4 + 4 * rnd);
     });
+    if constexpr (!KSP) {                                       // a tile pass lies inside ONE image
+      if (a.amax_out || a.amax_act) {
+        const unsigned mo = __builtin_bit_cast(unsigned, ipdm_wave_max(amx_o)), ma = __builtin_bit_cast(unsigned, ipdm_wave_max(amx_a));
+        const unsigned uo = __builtin_amdgcn_readfirstlane(mo), ua = __builtin_amdgcn_readfirstlane(ma);
+        pend_o = pend_o > uo ? pend_o : uo;
+        pend_a = pend_a > ua ? pend_a : ua;
+      }
+    }
 #ifdef IPDM_WBX3_TRACE
     ++tiles_done;
 #endif
     if (!has_next) break;
     zero_acc();
     tile = next_tile;
+    if (next_g.b != cur_g.b) hx_scales_of(next_g.b, hx_in, hx_out);
     cur_g = next_g;
-    hx_scales_of(cur_g.b, hx_in, hx_out);
   }
+  if constexpr (!KSP) flush_amax();
   if (a.dbg) {
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long t3 = __builtin_amdgcn_s_memtime();
@@ -1611,6 +1666,9 @@ static int conv_wino_bx3_launch_ksplit_t(ConvArgs a, int ksplit, float* work, hi
   a.co_tiles = a.Cout / X_CO;
   a.ksplit = ksplit;
   a.bias = nullptr; a.residual = nullptr; a.out_act = nullptr; a.out = work; a.pool2 = 0; a.stats = nullptr;
+  float* const amax_out = a.amax_out;
+  float* const amax_act = a.amax_act;
+  a.amax_out = a.amax_act = nullptr;              // the parts are partial sums: the maxima belong to the reduce pass
   const float out_scale = a.out_scale;
   a.out_scale = 1.f;                              // the parts are raw sums: bias / residual / scale belong to the reduce pass
   const int64_t nblk = (int64_t)a.B * a.tiles_x * a.tiles_y * a.co_tiles * ksplit;
@@ -1626,8 +1684,8 @@ static int conv_wino_bx3_launch_ksplit_t(ConvArgs a, int ksplit, float* work, hi
   hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<HXV, 8, 8, true, true, false, false, true>), dim3((unsigned)(8 * S)), dim3(512),
                      X_LDS_BYTES, s, a, (int)nblk);
   const int64_t plane = (int64_t)a.H * a.W, total = (int64_t)a.B * a.Cout * plane;
-  hipLaunchKernelGGL(bx3_splitk_reduce_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, s, work, ksplit, bias, residual,
-                     out, out_act, a.act_out, a.Cout, plane, total, a.bias_bstride, out_scale);
+  hipLaunchKernelGGL(bx3_splitk_reduce_kernel, splitk_reduce_grid(a.B, (int64_t)a.Cout * plane, amax_out || amax_act), dim3(256), 0, s, work, ksplit, bias, residual,
+                     out, out_act, a.act_out, a.Cout, plane, total, a.bias_bstride, out_scale, amax_out, amax_act);
   return ipdm_launch_status();
 }
 
@@ -1724,6 +1782,7 @@ static int wino_bx3_splitk_entry(const float* x, const void* U, const float* bia
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && dilation >= 1 && ksplit >= 2);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && U && work && (out || out_act) && x != out && x != out_act);
+  IPDM_REQUIRE(B <= 65535 || !ext || (!ext->out_amax && !ext->act_amax));
   ConvArgs a;
   a.x = x; a.wt = (const float*)U; a.bias = bias; a.coef = nullptr; a.residual = residual; a.out = out; a.out_act = out_act;
   a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = dilation; a.act = IPDM_ACT_NONE;

@@ -58,6 +58,61 @@ __device__ __forceinline__ double ipdm_wave_sum(double v) {
   return v;
 }
 
+// ---- per-image activation maxima (the f16x2 convolutions' dynamic range; include/ipdm.h, "maxima vectors") ----------------
+// A maxima vector is [B][IPDM_AMAX_SLOT] floats: eight WAYS per image, one 64-byte line each (the first float of the line).
+// Producers accumulate max |value| with atomic max into the way of their wave; a consumer takes the max over the eight ways.
+// Why ways, and why a line each: float atomics execute at the memory side and serialise per 64-byte LINE (~26 ns each); the
+// persistent convolution kernels finish a tile pass on all CUs at once, 256 waves per image, and vmcnt retires in order -- with
+// one word per image every later load of those waves waited microseconds for its own atomic (measured: +18 % convolution time).
+constexpr int IPDM_AMAX_WAY_STRIDE = 16;                        // floats between ways
+
+__device__ __forceinline__ float ipdm_wave_max(float v) {       // v >= 0 in every lane; the maximum in every lane
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false)));
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+// |v| >= 0: the unsigned order of the bit patterns is the float order; max is exact and order-independent (deterministic)
+__device__ __forceinline__ void ipdm_amax_atomic(float* image_slot, int way, float m) {
+  atomicMax(reinterpret_cast<unsigned*>(image_slot + (way & (IPDM_AMAX_WAYS - 1)) * IPDM_AMAX_WAY_STRIDE), __builtin_bit_cast(unsigned, m));
+}
+// per-thread maximum -> ONE atomic per wave on the image's slot (way = the wave's global index)
+__device__ __forceinline__ void ipdm_amax_commit(float m, float* image_slot, int way) {
+  m = ipdm_wave_max(m);
+  if ((threadIdx.x & 63) == 0) ipdm_amax_atomic(image_slot, way, m);
+}
+// per-thread maximum -> ONE atomic per 256-thread WORKGROUP (simple kernels with LDS to spare; `red`: four floats of LDS);
+// every thread of the workgroup must call it
+__device__ __forceinline__ void ipdm_amax_commit_block(float m, float* image_slot, int way, float* red) {
+  m = ipdm_wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) ipdm_amax_atomic(image_slot, way, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+// consumer, vector form: lanes 0..7 load a way each, wave max -> the image's value in every lane (the loads are ordinary VMEM:
+// the compiler overlaps them with the kernel's other prologue loads; one image per workgroup)
+__device__ __forceinline__ float ipdm_amax_read_v(const float* image_slot) {
+  const int lane = threadIdx.x & 63;
+  const float v = image_slot[(lane & (IPDM_AMAX_WAYS - 1)) * IPDM_AMAX_WAY_STRIDE];
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ipdm_wave_max(v))));
+}
+// consumer: max over the ways of one image (wave-uniform address: eight scalar loads)
+__device__ __forceinline__ float ipdm_amax_read(const float* image_slot) {
+  unsigned w0, w1, w2, w3, w4, w5, w6, w7;
+  asm volatile(
+      "s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\ts_load_dword %3, %8, 0xc0\n\t"
+      "s_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\ts_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(w0), "=&s"(w1), "=&s"(w2), "=&s"(w3), "=&s"(w4), "=&s"(w5), "=&s"(w6), "=&s"(w7)
+      : "s"(image_slot)
+      : "memory");
+  const unsigned a = w0 > w1 ? w0 : w1, b = w2 > w3 ? w2 : w3, c = w4 > w5 ? w4 : w5, d = w6 > w7 ? w6 : w7;
+  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+  return __builtin_bit_cast(float, ab > cd ? ab : cd);
+}
+
 // ---- Philox4x32-10 counter-based generator --------------------------------------------------
 // key     = (seed lo, seed hi)                      -- the seed alone: two seeds never share a stream
 // counter = (quad index within the plane, step lo, sample id lo, plane | step bits 32..39 << 8 | sample id bits 32..47 << 16)

@@ -113,11 +113,17 @@ __global__ __launch_bounds__(256) void plane_stats_small_kernel(const float* __r
 
 // pass 2: one workgroup per image: cross-channel mean / unbiased variance of the plane means, then
 // coef[b][c] = (mu, gamma*rstd, beta + gamma*alpha*(mu - m)/sqrt(v + 1e-5))
+// amax_bound (optional, a maxima vector [B][IPDM_AMAX_SLOT]): an upper bound of max |normalised value| over the image, from the coefficients alone --
+// |x - mu| * rstd < sqrt(HW) for every element of a plane (n - 1 squared deviations cannot exceed n times the variance), so
+// |(x - mu) * scale + shift| < |scale / rstd| * sqrt(HW) + |shift|, and every activation code shrinks |.|.  What the consuming
+// f16x2 convolution takes as in_amax (conv_kernel.h, hx_dynamic_scale): a bound is enough there, and this one costs nothing.
 __global__ __launch_bounds__(256) void instnorm_plus_coef_kernel(float* __restrict__ coef,
                                                                  const float* __restrict__ alpha,
                                                                  const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, int C) {
+                                                                 const float* __restrict__ beta, int C,
+                                                                 float* __restrict__ amax_bound, float sqrt_hw) {
   __shared__ double red[4];
+  __shared__ float redf[4];
   float* cb = coef + (size_t)blockIdx.x * C * 3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double s = 0.0;
@@ -137,12 +143,23 @@ __global__ __launch_bounds__(256) void instnorm_plus_coef_kernel(float* __restri
   __syncthreads();
   const float v = (float)((red[0] + red[1] + red[2] + red[3]) / (double)(C - 1));   // C == 1 -> NaN, as torch.var
   const float inv = 1.0f / sqrtf(v + 1e-5f);
+  float bound = 0.f;
   for (int c = tid; c < C; c += 256) {
     float mu = cb[c * 3], rstd = cb[c * 3 + 1];
     float g = gamma[c];
     float mn = (mu - m) * inv;
+    const float shift = (beta ? beta[c] : 0.f) + g * (mn * alpha[c]);
     cb[c * 3 + 1] = g * rstd;
-    cb[c * 3 + 2] = (beta ? beta[c] : 0.f) + g * (mn * alpha[c]);
+    cb[c * 3 + 2] = shift;
+    bound = fmaxf(bound, fabsf(g) * sqrt_hw + fabsf(shift));
+  }
+  if (amax_bound) {                                            // (uniform)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o, 64));
+    if (lane == 0) redf[wave] = bound;
+    __syncthreads();
+    if (tid < IPDM_AMAX_WAYS)                                    // every way of the image's slot: no zeroing needed
+      amax_bound[(size_t)blockIdx.x * IPDM_AMAX_SLOT + tid * IPDM_AMAX_WAY_STRIDE] = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
   }
 }
 
@@ -374,9 +391,20 @@ __global__ __launch_bounds__(256) void meanpool2_kernel(const float* __restrict_
   }
 }
 
+// max |written value| of a thread -> one atomic max per wave on the image's slot of a maxima vector (ipdm_common.h)
+__device__ __forceinline__ void amax_commit(float m, float* image_slot, int way) {
+  __shared__ float red[4];
+  ipdm_amax_commit_block(m, image_slot, way, red);
+}
+
+// (grid.y = images when amax is wanted: a workgroup then stays inside one image; n_out = outputs per grid.y slice)
 __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ x, float* out, int64_t n_out, int ih,
-                                                       int iw, int oh, int ow, float sh, float sw, int accumulate, int act) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * 256) {
+                                                       int iw, int oh, int ow, float sh, float sw, int accumulate, int act,
+                                                       float* amax) {
+  float amx = 0.f;
+  const int64_t base = (int64_t)blockIdx.y * n_out;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n_out; k += (int64_t)gridDim.x * 256) {
+    const int64_t i = base + k;
     int ox = (int)(i % ow);
     int64_t t = i / ow;
     int oy = (int)(t % oh);
@@ -389,16 +417,23 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__
     const float* p = x + plane * (int64_t)ih * iw;
     float v = ly0 * (lx0 * p[y0 * iw + x0] + lx1 * p[y0 * iw + x0 + xp]) +
               ly1 * (lx0 * p[(y0 + yp) * iw + x0] + lx1 * p[(y0 + yp) * iw + x0 + xp]);
-    out[i] = ipdm_act(accumulate ? out[i] + v : v, act);
+    const float r = ipdm_act(accumulate ? out[i] + v : v, act);
+    amx = fmaxf(amx, fabsf(r));
+    out[i] = r;
   }
+  if (amax) amax_commit(amx, amax + (size_t)blockIdx.y * IPDM_AMAX_SLOT, (int)blockIdx.x);
 }
 
 // ow % 4 == 0: four adjacent outputs per thread (one row / plane decomposition, float4 read-modify-write of `out`);
 // per-element arithmetic identical to bilinear_kernel
 __global__ __launch_bounds__(256) void bilinear4_kernel(const float* __restrict__ x, float* out, int64_t n_items, int ih,
-                                                        int iw, int oh, int ow, float sh, float sw, int accumulate, int act) {
+                                                        int iw, int oh, int ow, float sh, float sw, int accumulate, int act,
+                                                        float* amax) {
   const int og = ow / 4;
-  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < n_items; it += (int64_t)gridDim.x * 256) {
+  float amx = 0.f;
+  const int64_t base = (int64_t)blockIdx.y * n_items;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n_items; k += (int64_t)gridDim.x * 256) {
+    const int64_t it = base + k;
     const int xg = (int)(it % og);
     const int64_t t = it / og;
     const int oy = (int)(t % oh);
@@ -426,8 +461,10 @@ __global__ __launch_bounds__(256) void bilinear4_kernel(const float* __restrict_
     o.y = ipdm_act(accumulate ? acc.y + res[1] : res[1], act);
     o.z = ipdm_act(accumulate ? acc.z + res[2] : res[2], act);
     o.w = ipdm_act(accumulate ? acc.w + res[3] : res[3], act);
+    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     *reinterpret_cast<float4*>(po) = o;
   }
+  if (amax) amax_commit(amx, amax + (size_t)blockIdx.y * IPDM_AMAX_SLOT, (int)blockIdx.x);
 }
 
 struct ActOp {
@@ -442,7 +479,7 @@ struct ScaleShiftOp {
 }  // namespace
 
 extern "C" int ipdm_instnorm_plus_coef_f32(const float* x, const float* alpha, const float* gamma, const float* beta,
-                                           float* coef, int B, int C, int HW, void* stream) {
+                                           float* coef, int B, int C, int HW, float* amax_bound, void* stream) {
   IPDM_REQUIRE(B >= 0 && C > 0 && HW > 0);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && alpha && gamma && coef);
@@ -454,18 +491,21 @@ extern "C" int ipdm_instnorm_plus_coef_f32(const float* x, const float* alpha, c
     hipLaunchKernelGGL(plane_stats_kernel<true>, dim3(B * C), dim3(256), 0, s, x, coef, HW);
   else
     hipLaunchKernelGGL(plane_stats_kernel<false>, dim3(B * C), dim3(256), 0, s, x, coef, HW);
-  hipLaunchKernelGGL(instnorm_plus_coef_kernel, dim3(B), dim3(256), 0, s, coef, alpha, gamma, beta, C);
+  hipLaunchKernelGGL(instnorm_plus_coef_kernel, dim3(B), dim3(256), 0, s, coef, alpha, gamma, beta, C, amax_bound,
+                     sqrtf((float)HW));
   return ipdm_launch_status();
 }
 
 extern "C" int ipdm_instnorm_plus_coef_partials_f32(const float* partials, int P, const float* alpha, const float* gamma,
-                                                    const float* beta, float* coef, int B, int C, void* stream) {
-  IPDM_REQUIRE(B >= 0 && C > 0 && P > 0);
+                                                    const float* beta, float* coef, int B, int C, int HW, float* amax_bound,
+                                                    void* stream) {
+  IPDM_REQUIRE(B >= 0 && C > 0 && P > 0 && (HW > 0 || !amax_bound));
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(partials && alpha && gamma && coef);
   hipStream_t s = ipdm_stream(stream);
   hipLaunchKernelGGL(plane_stats_from_partials_kernel, dim3((B * C + 3) / 4), dim3(256), 0, s, partials, coef, B * C, P);
-  hipLaunchKernelGGL(instnorm_plus_coef_kernel, dim3(B), dim3(256), 0, s, coef, alpha, gamma, beta, C);
+  hipLaunchKernelGGL(instnorm_plus_coef_kernel, dim3(B), dim3(256), 0, s, coef, alpha, gamma, beta, C, amax_bound,
+                     sqrtf((float)(HW > 0 ? HW : 0)));
   return ipdm_launch_status();
 }
 
@@ -577,7 +617,9 @@ extern "C" int ipdm_meanpool2_f32(const float* x, float* y, int planes, int H, i
 // bilinear_kernel.  LDS: (floor(sh*(RB-1)) + 3) * in_w floats, checked by the launcher.
 constexpr int BL_RB = 16;                       // output rows per strip
 __global__ __launch_bounds__(256) void bilinear_lds_kernel(const float* __restrict__ x, float* out, int ih, int iw, int oh,
-                                                           int ow, float sh, float sw, int accumulate, int act, int lds_rows) {
+                                                           int ow, float sh, float sw, int accumulate, int act, int lds_rows,
+                                                           float* amax, int planes_per_image) {
+  float amx = 0.f;
   extern __shared__ __align__(16) float bl_src[];
   const int64_t plane = blockIdx.y;
   const int r0 = blockIdx.x * BL_RB;
@@ -616,15 +658,20 @@ __global__ __launch_bounds__(256) void bilinear_lds_kernel(const float* __restri
     o.y = ipdm_act(accumulate ? acc.y + res[1] : res[1], act);
     o.z = ipdm_act(accumulate ? acc.z + res[2] : res[2], act);
     o.w = ipdm_act(accumulate ? acc.w + res[3] : res[3], act);
+    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     *reinterpret_cast<float4*>(po) = o;
   }
+  if (amax) amax_commit(amx, amax + (size_t)(plane / planes_per_image) * IPDM_AMAX_SLOT, (int)(blockIdx.x + blockIdx.y));
 }
 
 extern "C" int ipdm_bilinear_f32(const float* x, float* out, int planes, int in_h, int in_w, int out_h, int out_w,
-                                 int accumulate, int act, void* stream) {
+                                 int accumulate, int act, int planes_per_image, float* amax_out, void* stream) {
   IPDM_REQUIRE(planes >= 0 && in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0);
   if (planes == 0) return IPDM_OK;
   IPDM_REQUIRE(x && out);
+  IPDM_REQUIRE(!amax_out || (planes_per_image > 0 && planes % planes_per_image == 0 && planes / planes_per_image <= 65535));
+  const int n_img = amax_out ? planes / planes_per_image : 1;       // grid.y of the grid-stride forms
+  const int ppi = amax_out ? planes_per_image : 1;
   float sh = out_h > 1 ? (float)(in_h - 1) / (float)(out_h - 1) : 0.f;
   float sw = out_w > 1 ? (float)(in_w - 1) / (float)(out_w - 1) : 0.f;
   int64_t n_out = (int64_t)planes * out_h * out_w;
@@ -634,15 +681,21 @@ extern "C" int ipdm_bilinear_f32(const float* x, float* out, int planes, int in_
       (size_t)lds_rows * in_w * sizeof(float) <= 48 * 1024) {
     hipLaunchKernelGGL(bilinear_lds_kernel, dim3((out_h + BL_RB - 1) / BL_RB, planes), dim3(256),
                        (size_t)lds_rows * in_w * sizeof(float), ipdm_stream(stream), x, out, in_h, in_w, out_h, out_w, sh, sw,
-                       accumulate, act, lds_rows);
+                       accumulate, act, lds_rows, amax_out, ppi);
     return ipdm_launch_status();
   }
+  auto grid = [&](int64_t per_slice) {                               // ~2048 workgroups in all
+    int64_t gx = (per_slice + 255) / 256, cap = (2048 + n_img - 1) / n_img;
+    gx = gx < 1 ? 1 : (gx > cap ? cap : gx);
+    return dim3((unsigned)gx, (unsigned)n_img);
+  };
   if (out_w % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-    hipLaunchKernelGGL(bilinear4_kernel, dim3(ipdm_ew_grid(n_out / 4, 256)), dim3(256), 0, ipdm_stream(stream), x, out,
-                       (long long)(n_out / 4), in_h, in_w, out_h, out_w, sh, sw, accumulate, act);
+    const int64_t per = n_out / 4 / n_img;
+    hipLaunchKernelGGL(bilinear4_kernel, grid(per), dim3(256), 0, ipdm_stream(stream), x, out, (long long)per, in_h, in_w,
+                       out_h, out_w, sh, sw, accumulate, act, amax_out);
     return ipdm_launch_status();
   }
-  hipLaunchKernelGGL(bilinear_kernel, dim3(ipdm_ew_grid(n_out, 256)), dim3(256), 0, ipdm_stream(stream), x, out,
-                     (long long)n_out, in_h, in_w, out_h, out_w, sh, sw, accumulate, act);
+  hipLaunchKernelGGL(bilinear_kernel, grid(n_out / n_img), dim3(256), 0, ipdm_stream(stream), x, out, (long long)(n_out / n_img),
+                     in_h, in_w, out_h, out_w, sh, sw, accumulate, act, amax_out);
   return ipdm_launch_status();
 }

@@ -1,6 +1,6 @@
-// Per-image max |x| of an activation tensor: the input of the f16x2 convolutions' dynamic range (conv_kernel.h,
-// hx_dynamic_scale).  One HBM pass (4 B per element, float4 loads), a wave reduction and one atomicMax per wave on the
-// image's slot (|x| >= 0, so the unsigned order of the bit patterns is the float order).  The slots are zeroed by the same
+// Per-image max |x| of an activation tensor as a maxima vector ([B][IPDM_AMAX_SLOT], ipdm.h): the input of the f16x2
+// convolutions' dynamic range (conv_kernel.h, hx_dynamic_scale) where no producer handed the maxima over.  One HBM pass (4 B per
+// element, float4 loads), a wave reduction and one atomic max per wave on a way of the image's slot.  The vector is zeroed by the same
 // call (hipMemsetAsync: a memset node under graph capture).  NaN inputs are ignored by the max (the convolution then produces
 // NaN outputs from them as any fp32 convolution would).
 #include "ipdm_common.h"
@@ -24,9 +24,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   for (; i < n4; i += stride) m0 = fmaxf(m0, am4(p4[i]));
   float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
   for (int64_t k = n4 * 4 + (int64_t)blk * 256 + threadIdx.x; k < per_image; k += stride) m = fmaxf(m, fabsf(p[k]));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(amax + img, __float_as_uint(m));
+  ipdm_amax_commit(m, reinterpret_cast<float*>(amax) + (size_t)img * IPDM_AMAX_SLOT, (int)(blk * 4 + (threadIdx.x >> 6)));
 }
 
 }  // namespace
@@ -36,7 +34,7 @@ extern "C" int ipdm_absmax_f32(const float* x, float* amax, int n_images, int64_
   if (n_images == 0) return IPDM_OK;
   IPDM_REQUIRE(amax && (x || per_image == 0));
   hipStream_t s = ipdm_stream(stream);
-  hipError_t e = hipMemsetAsync(amax, 0, (size_t)n_images * sizeof(float), s);
+  hipError_t e = hipMemsetAsync(amax, 0, (size_t)n_images * IPDM_AMAX_SLOT * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
   if (per_image == 0) return IPDM_OK;
   int64_t bpi = (per_image / 4 + 255) / 256;                  // one float4 per thread and trip ...

@@ -77,8 +77,12 @@ __global__ __launch_bounds__(256) void temporal_taps_kernel(const float* __restr
 // output element per thread, the eight taps combined in ATen's order (width, then height, then depth)
 __global__ __launch_bounds__(256) void trilinear_kernel(const float* __restrict__ x, float* out, long long total, int id,
                                                         int ih, int iw, int od, int oh, int ow, float sd, float sh, float sw,
-                                                        int accumulate, int act) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+                                                        int accumulate, int act, float* amax) {
+  // (grid.y = images when amax is wanted; total = outputs per grid.y slice)
+  float amx = 0.f;
+  const long long base = (long long)blockIdx.y * total;
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long long)gridDim.x * 256) {
+    const long long i = base + k;
     const int ox = (int)(i % ow);
     long long t = i / ow;
     const int oy = (int)(t % oh);
@@ -96,8 +100,12 @@ __global__ __launch_bounds__(256) void trilinear_kernel(const float* __restrict_
     float v = lz0 * (ly0 * (lx0 * p00[0] + lx1 * p00[xp]) + ly1 * (lx0 * p01[0] + lx1 * p01[xp])) +
               lz1 * (ly0 * (lx0 * p10[0] + lx1 * p10[xp]) + ly1 * (lx0 * p11[0] + lx1 * p11[xp]));
     if (accumulate) v += out[i];
-    out[i] = ipdm_act(v, act);
+    v = ipdm_act(v, act);
+    amx = fmaxf(amx, fabsf(v));
+    out[i] = v;
   }
+  __shared__ float red[4];
+  if (amax) ipdm_amax_commit_block(amx, amax + (size_t)blockIdx.y * IPDM_AMAX_SLOT, (int)blockIdx.x, red);
 }
 
 }  // namespace
@@ -124,15 +132,20 @@ extern "C" int ipdm_temporal_taps_f32(const float* x, float* out, int planes, in
 }
 
 extern "C" int ipdm_trilinear_f32(const float* x, float* out, int planes, int in_d, int in_h, int in_w, int out_d, int out_h,
-                                  int out_w, int accumulate, int act, void* stream) {
+                                  int out_w, int accumulate, int act, int planes_per_image, float* amax_out, void* stream) {
   IPDM_REQUIRE(planes >= 0 && in_d > 0 && in_h > 0 && in_w > 0 && out_d > 0 && out_h > 0 && out_w > 0);
   if (planes == 0) return IPDM_OK;
   IPDM_REQUIRE(x && out && x != out);
+  IPDM_REQUIRE(!amax_out || (planes_per_image > 0 && planes % planes_per_image == 0 && planes / planes_per_image <= 65535));
+  const int n_img = amax_out ? planes / planes_per_image : 1;
   const float sd = out_d > 1 ? (float)(in_d - 1) / (float)(out_d - 1) : 0.f;
   const float sh = out_h > 1 ? (float)(in_h - 1) / (float)(out_h - 1) : 0.f;
   const float sw = out_w > 1 ? (float)(in_w - 1) / (float)(out_w - 1) : 0.f;
   const int64_t total = (int64_t)planes * out_d * out_h * out_w;
-  hipLaunchKernelGGL(trilinear_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, ipdm_stream(stream), x, out,
-                     (long long)total, in_d, in_h, in_w, out_d, out_h, out_w, sd, sh, sw, accumulate, act);
+  const int64_t per = total / n_img;
+  int64_t gx = (per + 255) / 256, cap = (2048 + n_img - 1) / n_img;
+  gx = gx < 1 ? 1 : (gx > cap ? cap : gx);
+  hipLaunchKernelGGL(trilinear_kernel, dim3((unsigned)gx, (unsigned)n_img), dim3(256), 0, ipdm_stream(stream), x, out,
+                     (long long)per, in_d, in_h, in_w, out_d, out_h, out_w, sd, sh, sw, accumulate, act, amax_out);
   return ipdm_launch_status();
 }

@@ -58,11 +58,14 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
     """stride-1 'same' convolution, kernel 1 or 3, optional dilation; weight in the reference's layout
     [Cout, Cin, k, k] (what checkpoints carry), repacked once for the selected kernel family (ops.conv_weight)."""
 
-    def __init__(self, in_planes, out_planes, kernel_size=3, dilation=1, bias=True, ndim=2):
+    def __init__(self, in_planes, out_planes, kernel_size=3, dilation=1, bias=True, ndim=2, full_range=False):
+        """full_range: the layer reads a RAW network input through a fused input transform (begin_conv's `2x - 1`), whose range no
+        producer bounds: on the f16x2 family it runs the three-piece bf16 kernels instead (the whole fp32 exponent range)"""
         super().__init__()
         assert kernel_size in (1, 3) and ndim in (2, 3)
         self.in_planes, self.out_planes, self.kernel_size, self.dilation = in_planes, out_planes, kernel_size, dilation
         self.ndim = ndim
+        self.full_range = full_range
         self.weight = nn.Parameter(torch.empty(out_planes, in_planes, *([kernel_size] * ndim)))
         self.bias = nn.Parameter(torch.empty(out_planes)) if bias else None
         bound = 1.0 / (in_planes * kernel_size ** ndim) ** 0.5
@@ -81,13 +84,24 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
         return self._cached("wino_" + ops.CONV_IMPL, ops.conv_wino_split_weight)
 
     def packed(self):
+        if self.full_range and ops.CONV_IMPL == "hx2":
+            return self._cached("direct_bx3", lambda w: ops.conv_weight(w, impl="bx3"))
         return self._cached("direct_" + ops.CONV_IMPL, ops.conv_weight)
 
     def forward(self, x, coef=None, act=ops.ACT_NONE, residual=None, out=None, act_out=ops.ACT_NONE, raw=True,
-                want_stats=False):
+                want_stats=False, in_amax=None, feeds_conv=True):
         """want_stats: the result goes into an InstanceNorm++ next (the Winograd kernel's statistics epilogue then spares
-        that normalisation its pass over the tensor; ignored by the other kernels)"""
+        that normalisation its pass over the tensor; ignored by the other kernels).
+        f16x2 family: the input's per-image maxima come with the tensor from its producer (ops.in_amax_for; `in_amax` overrides)
+        and this layer's epilogue accumulates the maxima of what it stores for ITS consumer -- every convolution of the network
+        then runs with the dynamic range (any fp32 input is in range) at no pass over any tensor.
+        feeds_conv=False: the result is read by normalisations / residual adds / resizes only (they bound or measure what THEY
+        hand on), so the epilogue skips the maxima -- an atomic at the end of a launch costs its round trip (~2.5 us)."""
         bias = None if self.bias is None else self.bias.data
+        dyn = ops.dynamic_range()
+        produce = dyn and feeds_conv
+        if in_amax is None and dyn and coef is None and act == ops.ACT_NONE:
+            in_amax = ops.in_amax_for(x)
         if (self.ndim == 2 and self.kernel_size == 3 and self.dilation == 1 and act == ops.ACT_NONE
                 and residual is None and out is None and act_out == ops.ACT_NONE and raw and x.dim() == 4
                 and (self.in_planes <= 3 or (self.out_planes <= 3 and coef is None))
@@ -102,10 +116,12 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
                 and act == ops.ACT_NONE and out is None and ops.wino_bx3_pays(self.in_planes, self.out_planes, x.shape[2],
                                                                               x.shape[3], self.dilation)):
             return ops.conv2d_wino_bx3(x, self.packed_wino_bx3(), bias, residual, act_out=act_out, raw=raw,
-                                       dilation=self.dilation, want_stats=want_stats)
+                                       dilation=self.dilation, want_stats=want_stats, in_amax=in_amax, want_amax=produce)
         if self.ndim == 3:
-            return ops.conv3d(x, self.packed(), bias, coef, act, residual, self.dilation, act_out=act_out, raw=raw)
-        return ops.conv2d(x, self.packed(), bias, coef, act, residual, self.dilation, out=out, act_out=act_out, raw=raw)
+            return ops.conv3d(x, self.packed(), bias, coef, act, residual, self.dilation, act_out=act_out, raw=raw,
+                              in_amax=in_amax, want_amax=produce)
+        return ops.conv2d(x, self.packed(), bias, coef, act, residual, self.dilation, out=out, act_out=act_out, raw=raw,
+                          in_amax=in_amax, want_amax=produce)
 
 
 def conv1x1(in_planes, out_planes, stride=1, bias=True, spec_norm=False, ndim=2):
@@ -136,14 +152,14 @@ class ConvMeanPool(nn.Module):
             raise NotImplementedError("the 8-way 3-D ConvMeanPool is unused by NCSN3DShallow (all its stages are dilated)")
         self.conv = Conv2d(input_dim, output_dim, kernel_size, bias=biases)
 
-    def forward(self, inputs):
+    def forward(self, inputs, feeds_conv=True):
         if self.conv.kernel_size == 1:
             # a 1x1 convolution (+ bias) commutes with the 2x2 mean: pool first, a quarter of the multiply-adds and of
             # the bytes (same value up to fp32 rounding order)
-            return self.conv(ops.meanpool2(inputs))
-        return ops.meanpool2(self.conv(inputs))
+            return self.conv(ops.meanpool2(inputs), feeds_conv=feeds_conv)
+        return ops.meanpool2(self.conv(inputs, feeds_conv=feeds_conv))
 
-    def fused(self, inputs, residual=None, act_out=ops.ACT_NONE):
+    def fused(self, inputs, residual=None, act_out=ops.ACT_NONE, feeds_conv=True):
         """3x3 ConvMeanPool (+ pooled-size residual, + activated copy) in ONE launch: the Winograd kernel's 2x2 output tile
         is the pooling window.  -> out or (out, out_act); None where the pooled epilogue is not built for this layer."""
         c = self.conv
@@ -153,7 +169,8 @@ class ConvMeanPool(nn.Module):
             return None
         try:
             return ops.conv2d_wino_bx3(inputs, c.packed_wino_bx3(), None if c.bias is None else c.bias.data, residual,
-                                       act_out=act_out, pool2=True, want_stats=True)     # a block's result: normalised next
+                                       act_out=act_out, pool2=True, want_stats=True,     # a block's result: normalised next
+                                       in_amax=ops.in_amax_for(inputs), want_amax=ops.dynamic_range() and feeds_conv)
         except _lib.IpdmUnsupported:
             return None
 
@@ -199,9 +216,10 @@ class RCUBlock(nn.Module):
         self.n_stages = n_stages
         self.act = act
 
-    def forward(self, x, x_act=None, want_act=False):
+    def forward(self, x, x_act=None, want_act=False, feeds_conv=True):
         """reference: per block  residual = x; (x = act(x); x = conv(x)) x n_stages; x += residual.
-        Inner stages only ever feed the next activation, so they write just the activated copy."""
+        Inner stages only ever feed the next activation, so they write just the activated copy.
+        feeds_conv=False: the block's RESULT is normalised next (the network's last RCU): no maxima for it."""
         code = _act_code(self.act)
         for i in range(self.n_blocks):
             residual = x
@@ -213,7 +231,7 @@ class RCUBlock(nn.Module):
                 elif i < self.n_blocks - 1 or want_act:
                     x, x_act = conv(a, residual=residual, act_out=code)
                 else:
-                    x, x_act = conv(a, residual=residual), None
+                    x, x_act = conv(a, residual=residual, feeds_conv=feeds_conv), None
         return x, x_act
 
 
@@ -235,11 +253,12 @@ class MSFBlock(nn.Module):
                 if last_act != ops.ACT_NONE:
                     _, sums = conv(xs[i], residual=sums, act_out=last_act, raw=False)
                 else:
-                    sums = conv(xs[i], residual=sums)
+                    sums = conv(xs[i], residual=sums, feeds_conv=False)      # only ever a residual / resize operand
             else:
-                h = conv(xs[i])
+                h = conv(xs[i], feeds_conv=False)
                 resize = ops.trilinear if h.dim() == 5 else ops.bilinear
-                sums = resize(h, shape, out=sums, accumulate=sums is not None, act=last_act)
+                sums = resize(h, shape, out=sums, accumulate=sums is not None, act=last_act,
+                              want_amax=i == n - 1 and ops.dynamic_range())      # the block's result feeds CRP's convolutions
         return sums
 
 
@@ -256,9 +275,10 @@ class RefineBlock(nn.Module):
         self.crp = CRPBlock(features, 2, act, maxpool=maxpool, spec_norm=spec_norm, ndim=ndim)
         self.act = act
 
-    def forward(self, xs, output_shape, xs_act=None, want_act=False):
+    def forward(self, xs, output_shape, xs_act=None, want_act=False, feeds_conv=None):
         """xs: raw inputs; xs_act: their activated copies where a producer emitted them (else None entries).
-        Returns the raw output, or (raw, activated) when want_act."""
+        Returns the raw output, or (raw, activated) when want_act.  feeds_conv (default: want_act): a convolution reads the result
+        (another refine block, a temporal convolution) -- otherwise it is normalised next and carries no maxima."""
         assert isinstance(xs, (tuple, list))
         code = _act_code(self.act)
         xs_act = [None] * len(xs) if xs_act is None else xs_act
@@ -269,7 +289,7 @@ class RefineBlock(nn.Module):
         else:
             a = self.msf([h[0] for h in hs], output_shape, act_out=code)
             h, h_act = self.crp(None, a, want_act=True)
-        out, out_act = self.output_convs(h, h_act, want_act=want_act)
+        out, out_act = self.output_convs(h, h_act, want_act=want_act, feeds_conv=want_act if feeds_conv is None else feeds_conv)
         return (out, out_act) if want_act else out
 
 
@@ -316,16 +336,18 @@ class ResidualBlock(nn.Module):
         self.normalize1 = normalization(input_dim)
 
     def forward(self, x, want_act=False):
-        """norm -> act -> conv1 -> norm -> act -> conv2 (+ shortcut).  want_act: also return act(out)."""
+        """norm -> act -> conv1 -> norm -> act -> conv2 (+ shortcut).  want_act: also return act(out) -- the last block of a
+        stage, whose result the next stage's shortcut convolution and the RefineNet branch read (the others' results meet
+        normalisations and residual adds only: no maxima needed)."""
         code = _act_code(self.non_linearity)
-        h = self.conv1(self.normalize1(x, code), want_stats=True)
+        h = self.conv1(self.normalize1(x, code), want_stats=True, feeds_conv=False)
         a2 = self.normalize2(h, code)
         if self.output_dim == self.input_dim and self.resample is None:
             shortcut = x
         else:
-            shortcut = self.shortcut(x)
+            shortcut = self.shortcut(x, feeds_conv=False)          # (a residual operand only)
         if isinstance(self.conv2, ConvMeanPool):
-            fused = self.conv2.fused(a2, residual=shortcut, act_out=code if want_act else ops.ACT_NONE)
+            fused = self.conv2.fused(a2, residual=shortcut, act_out=code if want_act else ops.ACT_NONE, feeds_conv=want_act)
             if fused is not None:                        # conv + 2x2 mean + shortcut (+ activated copy): one launch
                 return fused
             out = ops.add(shortcut, self.conv2(a2))
@@ -333,4 +355,4 @@ class ResidualBlock(nn.Module):
         # the block's result is what the next block normalises first
         if want_act:
             return self.conv2(a2, residual=shortcut, act_out=code, want_stats=True)
-        return self.conv2(a2, residual=shortcut, want_stats=True)
+        return self.conv2(a2, residual=shortcut, want_stats=True, feeds_conv=False)

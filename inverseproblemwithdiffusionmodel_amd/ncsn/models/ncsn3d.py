@@ -38,10 +38,12 @@ class _TemporalConv(ops.PackedWeightMixin, nn.Module):
 
     def forward(self, x):
         B, C, D, H, T = x.shape
-        taps = ops.temporal_taps(x, 1 if self.transposed else 0)            # [B, 4C, D, H, T']
+        taps = ops.temporal_taps(x, 1 if self.transposed else 0)            # [B, 4C, D, H, T']; carries x's maxima (a gather)
         Tn = taps.shape[-1]
-        y = ops.conv2d(taps.view(B, 4 * C, D * H, Tn), self.packed(), self.bias.data)
-        return y.view(B, self.out_ch, D, H, Tn)
+        dyn = ops.dynamic_range()
+        y = ops.conv2d(taps.view(B, 4 * C, D * H, Tn), self.packed(), self.bias.data,
+                       in_amax=ops.in_amax_for(taps) if dyn else None, want_amax=dyn)
+        return ops.carry_amax(y, y.view(B, self.out_ch, D, H, Tn))
 
 
 class NCSN3DShallow(nn.Module):
@@ -56,7 +58,7 @@ class NCSN3DShallow(nn.Module):
         self.register_buffer('sigmas', get_sigmas(config))
         self.config = config
         ch3 = config.data.channels_3d
-        self.begin_conv = Conv3d(ch3, ngf, 3)
+        self.begin_conv = Conv3d(ch3, ngf, 3, full_range=True)
         self.normalizer = self.norm(ngf)
         self.end_conv = Conv3d(ngf, ch3, 3)
         kw = dict(act=act, normalization=self.norm)
@@ -80,6 +82,10 @@ class NCSN3DShallow(nn.Module):
         return x
 
     def forward(self, x, y):
+        with ops.amax_scope():                           # one zero-fill for all the per-image maxima slots of the evaluation
+            return self._forward(x, y)
+
+    def _forward(self, x, y):
         if not x.is_cuda:
             raise RuntimeError("NCSN3DShallow: expected GPU tensors (no CPU fallback in this build)")
         x_dim = x.dim()
@@ -100,7 +106,7 @@ class NCSN3DShallow(nn.Module):
         layer3 = self.conv_temporal_down(layer2[0])                    # (B, 2ngf, 8, 8, T/2)
         layer4 = self._stage(self.res4, layer3)
         ref1 = self.refine1([layer4[0]], layer4[0].shape[2:], [layer4[1]], want_act=True)
-        ref2 = self.refine2([layer3, ref1[0]], layer3.shape[2:], [None, ref1[1]], want_act=False)
+        ref2 = self.refine2([layer3, ref1[0]], layer3.shape[2:], [None, ref1[1]], want_act=False, feeds_conv=True)
         ref3 = self.conv_temporal_up(ref2)                             # (B, ngf, 8, 8, T)
         output = self.refine3([layer1[0], ref3], layer1[0].shape[2:], [layer1[1], None], want_act=False)
         output = self.end_conv(self.normalizer(output, code))

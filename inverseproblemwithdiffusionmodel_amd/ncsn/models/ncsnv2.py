@@ -62,7 +62,7 @@ class NCSNv2Deepest(_NCSNv2Base):
     def __init__(self, config):
         super().__init__(config)
         ngf, ch = self.ngf, config.data.channels
-        self.begin_conv = Conv2d(ch, ngf, 3)
+        self.begin_conv = Conv2d(ch, ngf, 3, full_range=True)
         self.normalizer = self.norm(ngf)
         self.end_conv = Conv2d(ngf, ch, 3)
         self.res1 = self._stage(ngf, ngf)
@@ -79,6 +79,10 @@ class NCSNv2Deepest(_NCSNv2Base):
         self.refine5 = RefineBlock([ngf, ngf], ngf, act=self.act, end=True)
 
     def forward(self, x, y):
+        with ops.amax_scope():                           # one zero-fill for all the per-image maxima slots of the evaluation
+            return self._forward(x, y)
+
+    def _forward(self, x, y):
         output = self._begin(x)
         layer1 = self._compute_cond_module(self.res1, output)
         layer2 = self._compute_cond_module(self.res2, layer1[0])
@@ -99,7 +103,7 @@ class NCSNv2Deeper(_NCSNv2Base):
     def __init__(self, config):
         super().__init__(config)
         ngf, ch = self.ngf, config.data.channels
-        self.begin_conv = Conv2d(ch, ngf, 3)
+        self.begin_conv = Conv2d(ch, ngf, 3, full_range=True)
         self.normalizer = self.norm(ngf)
         self.end_conv = Conv2d(ngf, ch, 3)
         self.res1 = self._stage(ngf, ngf)
@@ -114,6 +118,10 @@ class NCSNv2Deeper(_NCSNv2Base):
         self.refine5 = RefineBlock([ngf, ngf], ngf, act=self.act, end=True)
 
     def forward(self, x, y):
+        with ops.amax_scope():                           # one zero-fill for all the per-image maxima slots of the evaluation
+            return self._forward(x, y)
+
+    def _forward(self, x, y):
         output = self._begin(x)
         layer1 = self._compute_cond_module(self.res1, output)
         layer2 = self._compute_cond_module(self.res2, layer1[0])
@@ -132,7 +140,7 @@ class NCSNv2(_NCSNv2Base):
     def __init__(self, config):
         super().__init__(config)
         ngf, ch = self.ngf, config.data.channels
-        self.begin_conv = Conv2d(ch, ngf, 3)
+        self.begin_conv = Conv2d(ch, ngf, 3, full_range=True)
         self.normalizer = self.norm(ngf)
         self.end_conv = Conv2d(ngf, ch, 3)
         self.res1 = self._stage(ngf, ngf)
@@ -147,6 +155,10 @@ class NCSNv2(_NCSNv2Base):
         self.refine4 = RefineBlock([ngf, ngf], ngf, act=self.act, end=True)
 
     def forward(self, x, y):
+        with ops.amax_scope():                           # one zero-fill for all the per-image maxima slots of the evaluation
+            return self._forward(x, y)
+
+    def _forward(self, x, y):
         output = self._begin(x)
         layer1 = self._compute_cond_module(self.res1, output)
         layer2 = self._compute_cond_module(self.res2, layer1[0])

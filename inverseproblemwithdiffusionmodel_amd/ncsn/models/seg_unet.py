@@ -57,7 +57,9 @@ class _Convolution(ops.PackedWeightMixin, nn.Module):
         """-> (y, saved) with saved = (xhat, rstd) or None"""
         if self.transposed and self.stride == 2:
             x = ops.zero_insert2(x)
-        c = ops.conv2d(x, self.packed("fwd"), self.conv.bias.data)
+        # (f16x2 family: every convolution here measures its input -- the state, InstanceNorm'ed activations and, on the way back,
+        #  gradients many orders of magnitude below 1 -- and runs with the dynamic range; ~2 % of a guided iteration)
+        c = ops.conv2d(x, self.packed("fwd"), self.conv.bias.data, in_amax=ops.in_amax_for(x))
         if not self.transposed and self.stride == 2:
             c = ops.subsample2(c)
         if self.conv_only:
@@ -70,7 +72,7 @@ class _Convolution(ops.PackedWeightMixin, nn.Module):
             g = ops.in_prelu_bwd(g, saved[0], saved[1], self.adn.A.weight.data)
         if not self.transposed and self.stride == 2:
             g = ops.zero_insert2(g)
-        g = ops.conv2d(g, self.packed("bwd"))
+        g = ops.conv2d(g, self.packed("bwd"), in_amax=ops.in_amax_for(g))
         if self.transposed and self.stride == 2:
             g = ops.subsample2(g)
         return g

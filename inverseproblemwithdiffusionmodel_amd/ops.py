@@ -436,6 +436,113 @@ def ssim(img, ref, data_range=2.0):
     return out
 
 
+# ---- per-image activation maxima: the f16x2 family's DYNAMIC RANGE without a pass over the tensor ------------------
+# An f16x2 convolution scales every image of its input into fp16's range by an exact power of two derived from an upper bound of
+# that image's max |x| (`in_amax`, conv_kernel.h hx_dynamic_scale) -- then ANY fp32 input is in range and values down to 2^-17 of
+# the bound keep all 22 significand bits.  The bounds come from the PRODUCERS: convolution epilogues and the resize kernels
+# accumulate the exact maxima of what they store with one atomic max per wave (`want_amax`), InstanceNorm++ / GroupNorm hand over
+# a bound computed from their coefficients, and pooling / activation / gather kernels pass their input's bound on (they never
+# increase |x|).  Maxima ride on the tensors as `_ipdm_amax = (amax [B], (version, data_ptr))`: a tensor written in place since
+# loses them, and a consumer that finds none MEASURES its input (ipdm_absmax_f32: one extra pass, counted in AMAX_MEASURED so that
+# tests can assert the hot path never does).  IPDM_HX2_DYNAMIC=0 restores round 3's static contract (|x| < 65504) for A/B runs.
+HX2_DYNAMIC = os.environ.get("IPDM_HX2_DYNAMIC", "1") != "0"
+AMAX_MEASURED = 0                               # fallback absmax passes since import (diagnostics / tests)
+
+
+def dynamic_range():
+    """True when convolutions should produce and consume per-image maxima (the f16x2 family with the dynamic range on)"""
+    return HX2_DYNAMIC and CONV_IMPL == "hx2"
+
+
+AMAX_WAYS, AMAX_SLOT = 8, 128                    # include/ipdm.h "maxima vectors": [B][AMAX_SLOT] floats, 8 ways per image, 16 floats apart
+
+
+def amax_value(am):
+    """maxima vector [B, AMAX_SLOT] -> per-image values [B] (the max over an image's ways)"""
+    return am.view(am.shape[0], AMAX_WAYS, AMAX_SLOT // AMAX_WAYS)[:, :, 0].amax(dim=1)
+
+
+class _AmaxArena:
+    """zeroed [slots][B][AMAX_SLOT] float32 block: ONE fill per block instead of one per vector (atomic-max ways start at zero)"""
+
+    def __init__(self, B, device, slots):
+        self.B, self.device, self.used, self.slots = B, device, 0, slots
+        self.buf = torch.zeros((slots, B, AMAX_SLOT), dtype=torch.float32, device=device)
+
+    def take(self):
+        if self.used == self.slots:
+            return None
+        self.used += 1
+        return self.buf[self.used - 1]
+
+
+_ARENAS = []                                    # stack of active amax_scope()s
+
+
+class amax_scope:
+    """`with ops.amax_scope():` around one network evaluation: the zeroed slots of every producer inside come out of a few large
+    blocks (one fill kernel per 256 slots).  Allocated INSIDE the scope, so a forward captured into a hipGraph re-zeroes its
+    slots on every replay.  Without a scope every slot is its own torch.zeros (correct, one more launch each)."""
+
+    def __enter__(self):
+        _ARENAS.append({})
+        return self
+
+    def __exit__(self, *exc):
+        _ARENAS.pop()
+        return False
+
+
+def amax_slot(B, device):
+    """a zeroed maxima vector (float32 [B, AMAX_SLOT]) for a producer's atomic maxima"""
+    if _ARENAS:
+        blocks = _ARENAS[-1]
+        key = (int(B), str(device))
+        a = blocks.get(key)
+        slot = a.take() if a is not None else None
+        if slot is None:
+            blocks[key] = a = _AmaxArena(int(B), device, 128)
+            slot = a.take()
+        return slot
+    return torch.zeros((int(B), AMAX_SLOT), dtype=torch.float32, device=device)
+
+
+def tag_amax(t, amax):
+    """attach per-image maxima (or an upper bound of them) to tensor t as it is NOW"""
+    if t is not None and amax is not None:
+        t._ipdm_amax = (amax, (t._version, t.data_ptr()))
+    return t
+
+
+def amax_of(t):
+    """the maxima attached to t, or None (never attached, or t was written in place since)"""
+    hit = getattr(t, "_ipdm_amax", None)
+    if hit is None:
+        return None
+    amax, tag = hit
+    if tag != (t._version, t.data_ptr()) or amax.shape[0] != t.shape[0]:
+        return None
+    return amax
+
+
+def carry_amax(src, dst):
+    """dst = f(src) with |f(x)| <= max |src| everywhere (pooling, activations, gathers, views): src's bound bounds dst"""
+    return tag_amax(dst, amax_of(src))
+
+
+def in_amax_for(x):
+    """the `in_amax` argument for a convolution reading x: None (static contract / other kernel families), the attached maxima,
+    or True = measure here (one pass, counted)"""
+    if not dynamic_range() or os.environ.get("IPDM_AMAX_CONSUME", "1") == "0":
+        return None
+    am = amax_of(x)
+    if am is not None:
+        return am
+    global AMAX_MEASURED
+    AMAX_MEASURED += 1
+    return True
+
+
 # ---- score-network glue -----------------------------------------------------------------------
 # the producing convolution's epilogue hands the plane statistics over as partials (conv2d_wino_bx3(want_stats=True) hangs
 # them on its result as `_ipdm_partials`), so that InstanceNorm++ does not read the tensor a second time
@@ -447,6 +554,11 @@ def instnorm_plus_coef(x, alpha, gamma, beta):
     x = _gpu(x, torch.float32, "x")
     B, C = x.shape[:2]
     coef = torch.empty((B, C, 3), dtype=torch.float32, device=x.device)
+    hw = x.numel() // max(B * C, 1)
+    # dynamic range: an upper bound of max |normalised value| per image, from the coefficients (affine_act passes it on)
+    bound = torch.empty((B, AMAX_SLOT), dtype=torch.float32, device=x.device) if dynamic_range() else None
+    if bound is not None:
+        coef._ipdm_amax_bound = bound
     part = getattr(x, "_ipdm_partials", None)
     if part is not None:
         del x._ipdm_partials             # single use: whatever touches the tensor afterwards cannot meet stale statistics
@@ -455,10 +567,10 @@ def instnorm_plus_coef(x, alpha, gamma, beta):
             part = None
     if part is not None and USE_STATS_EPILOGUE and tuple(part.shape[:2]) == (B, C):
         call("ipdm_instnorm_plus_coef_partials_f32", _ptr(part), int(part.shape[2]), _ptr(alpha), _ptr(gamma), _ptr(beta),
-             _ptr(coef), B, C, _stream())
+             _ptr(coef), B, C, hw, _ptr(bound), _stream())
         return coef
-    call("ipdm_instnorm_plus_coef_f32", _ptr(x), _ptr(alpha), _ptr(gamma), _ptr(beta), _ptr(coef), B, C,
-         x.numel() // max(B * C, 1), _stream())
+    call("ipdm_instnorm_plus_coef_f32", _ptr(x), _ptr(alpha), _ptr(gamma), _ptr(beta), _ptr(coef), B, C, hw, _ptr(bound),
+         _stream())
     return coef
 
 
@@ -467,14 +579,14 @@ def affine_act(x, coef, act=ACT_NONE, out=None):
     B, C = x.shape[:2]
     out = torch.empty_like(x) if out is None else out
     call("ipdm_affine_act_f32", _ptr(x), _ptr(coef), _ptr(out), B, C, x.numel() // max(B * C, 1), act, _stream())
-    return out
+    return tag_amax(out, getattr(coef, "_ipdm_amax_bound", None))     # (every activation code shrinks |.|)
 
 
 def act(x, code, out=None):
     x = _gpu(x, torch.float32, "x")
     out = torch.empty_like(x) if out is None else out
     call("ipdm_act_f32", _ptr(x), _ptr(out), x.numel(), code, _stream())
-    return out
+    return carry_amax(x, out)
 
 
 def scale_shift(x, a, b, out=None):
@@ -509,7 +621,7 @@ def maxpool5(x):
     B, C, H, W = x.shape
     out = torch.empty_like(x)
     call("ipdm_maxpool5_f32", _ptr(x), _ptr(out), B * C, H, W, _stream())
-    return out
+    return carry_amax(x, out)
 
 
 def meanpool2(x):
@@ -517,21 +629,23 @@ def meanpool2(x):
     B, C, H, W = x.shape
     out = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
     call("ipdm_meanpool2_f32", _ptr(x), _ptr(out), B * C, H, W, _stream())
-    return out
+    return carry_amax(x, out)
 
 
-def bilinear(x, size, out=None, accumulate=False, act=ACT_NONE):
+def bilinear(x, size, out=None, accumulate=False, act=ACT_NONE, want_amax=False):
+    """want_amax: the per-image maxima of what is written ride on the result (tag_amax)"""
     x = _gpu(x, torch.float32, "x")
     B, C, H, W = x.shape
     oh, ow = int(size[0]), int(size[1])
     if out is None:
         out = torch.empty((B, C, oh, ow), dtype=torch.float32, device=x.device)
         accumulate = False
-    call("ipdm_bilinear_f32", _ptr(x), _ptr(out), B * C, H, W, oh, ow, int(bool(accumulate)), act, _stream())
-    return out
+    slot = amax_slot(B, x.device) if want_amax and B <= 65535 else None
+    call("ipdm_bilinear_f32", _ptr(x), _ptr(out), B * C, H, W, oh, ow, int(bool(accumulate)), act, C, _ptr(slot), _stream())
+    return tag_amax(out, slot)
 
 
-def trilinear(x, size, out=None, accumulate=False, act=ACT_NONE):
+def trilinear(x, size, out=None, accumulate=False, act=ACT_NONE, want_amax=False):
     """F.interpolate(x, size, mode='trilinear', align_corners=True) of (B, C, D, H, W), optionally accumulated into out"""
     x = _gpu(x, torch.float32, "x")
     B, C, D, H, W = x.shape
@@ -539,8 +653,10 @@ def trilinear(x, size, out=None, accumulate=False, act=ACT_NONE):
     if out is None:
         out = torch.empty((B, C, od, oh, ow), dtype=torch.float32, device=x.device)
         accumulate = False
-    call("ipdm_trilinear_f32", _ptr(x), _ptr(out), B * C, D, H, W, od, oh, ow, int(bool(accumulate)), act, _stream())
-    return out
+    slot = amax_slot(B, x.device) if want_amax and B <= 65535 else None
+    call("ipdm_trilinear_f32", _ptr(x), _ptr(out), B * C, D, H, W, od, oh, ow, int(bool(accumulate)), act, C, _ptr(slot),
+         _stream())
+    return tag_amax(out, slot)
 
 
 # ---- NCSN++ / predictor-corrector extras --------------------------------------------------------
@@ -685,10 +801,12 @@ def conv2d_wino(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dila
     return (out, out_act) if want_act else out
 
 
-def conv3d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, act_out=ACT_NONE, raw=True):
+def conv3d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, act_out=ACT_NONE, raw=True, in_amax=None,
+           want_amax=False):
     """x [B,Cin,D,H,W]; wt packed [27 or 1, Cin, Cout]; same fused input/output options as conv2d"""
     if isinstance(wt, PackedBx3):
-        return conv_bx3(x, wt, bias, coef, act, residual, dilation, act_out=act_out, raw=raw)
+        return conv_bx3(x, wt, bias, coef, act, residual, dilation, act_out=act_out, raw=raw, in_amax=in_amax,
+                        want_amax=want_amax)
     x = _gpu(x, torch.float32, "x")
     B, Cin, D, H, W = x.shape
     kk, Cin_w, Cout = wt.shape
@@ -715,7 +833,7 @@ def maxpool3d5(x):
     B, C, D, H, W = x.shape
     out = torch.empty_like(x)
     call("ipdm_maxpool3d5_f32", _ptr(x), _ptr(out), B * C, D, H, W, _stream())
-    return out
+    return carry_amax(x, out)
 
 
 def temporal_taps(x, mode):
@@ -725,11 +843,11 @@ def temporal_taps(x, mode):
     T_out = T // 2 if mode == 0 else T * 2
     out = torch.empty((B, 4 * C, D, H, T_out), dtype=torch.float32, device=x.device)
     call("ipdm_temporal_taps_f32", _ptr(x), _ptr(out), B * C, D * H, T, T_out, mode, _stream())
-    return out
+    return carry_amax(x, out)
 
 
 def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, pool2=False, out=None,
-           act_out=ACT_NONE, raw=True, in_amax=None, out_scale=1.0):
+           act_out=ACT_NONE, raw=True, in_amax=None, out_scale=1.0, want_amax=False):
     """x [B,Cin,H,W]; wt packed [k*k,Cin,Cout].  Input side: optional InstanceNorm++ coefficients / activation.
     Output side: bias, residual add; act_out != NONE additionally returns the activated copy act_out(result)
     (raw=False: ONLY the activated copy is produced).  Returns out, or (out, out_act) when act_out is set
@@ -738,7 +856,7 @@ def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1,
         if pool2:
             raise _lib.IpdmUnsupported("conv2d: pool2 epilogue is not fused")
         return conv_bx3(x, wt, bias, coef, act, residual, dilation, out=out, act_out=act_out, raw=raw, in_amax=in_amax,
-                        out_scale=out_scale)
+                        out_scale=out_scale, want_amax=want_amax)
     if out_scale != 1.0 or (bias is not None and bias.dim() == 2):
         raise _lib.IpdmUnsupported("conv2d: per-image bias / out_scale exist on the split-operand kernels only")
     x = _gpu(x, torch.float32, "x")
@@ -884,30 +1002,34 @@ class PackedBx3:
 
 
 def absmax_per_image(x):
-    """per-image max |x| (float32 [B]) of an activation tensor: the `in_amax` of the f16x2 convolutions' dynamic range"""
+    """per-image max |x| of an activation tensor as a maxima vector (float32 [B, AMAX_SLOT]; amax_value() -> [B]): the `in_amax`
+    of the f16x2 convolutions' dynamic range where no producer handed the maxima over"""
     x = _gpu(x, torch.float32, "x")
     B = x.shape[0]
-    out = torch.empty(B, dtype=torch.float32, device=x.device)
+    out = torch.empty((B, AMAX_SLOT), dtype=torch.float32, device=x.device)
     call("ipdm_absmax_f32", _ptr(x), _ptr(out), B, x.numel() // max(B, 1), _stream())
     return out
 
 
-def _conv_ext(fmt, in_amax, x, fused_input, bias_per_image=False, out_scale=1.0, Cout=0):
+def _conv_ext(fmt, in_amax, x, fused_input, bias_per_image=False, out_scale=1.0, Cout=0, out_amax=None, act_amax=None):
     """-> the `ext` argument of the split-operand entry points (NULL when every extra is at its default).
     in_amax (hx2 blobs only): None -> static range contract; True -> measure the input here; a tensor -> as given (a fused input
     normalisation / activation makes the raw maximum meaningless: ignored).  bias_per_image: bias is [B, Cout].  out_scale:
-    result = (conv + bias + residual) * out_scale."""
+    result = (conv + bias + residual) * out_scale.  out_amax / act_amax: zeroed [B] slots for the maxima of what is stored."""
     amax_ptr = None
     if fmt == "hx2" and in_amax is not None and not fused_input:
         if in_amax is True:
             in_amax = absmax_per_image(x)
-        if in_amax.numel() != x.shape[0] or in_amax.dtype != torch.float32 or not in_amax.is_cuda:
-            raise ValueError("in_amax: expected a float32 GPU tensor with one entry per image")
+        if (tuple(in_amax.shape) != (x.shape[0], AMAX_SLOT) or in_amax.dtype != torch.float32 or not in_amax.is_cuda
+                or not in_amax.is_contiguous()):
+            raise ValueError(f"in_amax: expected a maxima vector -- contiguous float32 GPU tensor [{x.shape[0]}, {AMAX_SLOT}] "
+                             "(ops.absmax_per_image / a producer's tag)")
         amax_ptr = in_amax.data_ptr()
         _KEEP.append(in_amax)                    # (the kernel reads it asynchronously: keep the tensor alive until the call returns)
-    if amax_ptr is None and not bias_per_image and out_scale == 1.0:
+    if amax_ptr is None and not bias_per_image and out_scale == 1.0 and out_amax is None and act_amax is None:
         return P(0)
-    ext = _lib.ConvExt(amax_ptr, int(Cout) if bias_per_image else 0, float(out_scale))
+    ext = _lib.ConvExt(amax_ptr, int(Cout) if bias_per_image else 0, float(out_scale),
+                       None if out_amax is None else out_amax.data_ptr(), None if act_amax is None else act_amax.data_ptr())
     _KEEP.append(ext)
     del _KEEP[:-8]
     return ctypes.byref(ext)
@@ -942,7 +1064,7 @@ def conv_bx3_weight(w, fmt="bx3"):
 
 
 def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, out=None, act_out=ACT_NONE, raw=True,
-             in_amax=None, out_scale=1.0):
+             in_amax=None, out_scale=1.0, want_amax=False):
     """2-D ([B,Cin,H,W]) or 3-D ([B,Cin,D,H,W]) convolution, same options / return convention as conv2d / conv3d.
     in_amax (hx2 blobs only): None = static range contract |x| < 65504, True = measure the input (ipdm_absmax_f32) and scale every
     image into fp16's range, or the per-image maxima themselves"""
@@ -950,7 +1072,11 @@ def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=
     bias_per_image = bias is not None and bias.dim() == 2
     if bias_per_image and tuple(bias.shape) != (x.shape[0], wq.Cout):
         raise ValueError(f"conv_bx3: per-image bias {tuple(bias.shape)} != {(x.shape[0], wq.Cout)}")
-    ext = _conv_ext(wq.fmt, in_amax, x, coef is not None or act != ACT_NONE, bias_per_image, out_scale, wq.Cout)
+    want_act = act_out != ACT_NONE
+    want_amax = bool(want_amax) and x.shape[0] <= 65535 and os.environ.get("IPDM_AMAX_PRODUCE", "1") != "0"
+    slot_o = amax_slot(x.shape[0], x.device) if want_amax and raw else None
+    slot_a = amax_slot(x.shape[0], x.device) if want_amax and want_act else None
+    ext = _conv_ext(wq.fmt, in_amax, x, coef is not None or act != ACT_NONE, bias_per_image, out_scale, wq.Cout, slot_o, slot_a)
     if wq.Cin != x.shape[1]:
         raise ValueError(f"conv_bx3: weight Cin {wq.Cin} != input Cin {x.shape[1]}")
     vol = x.dim() == 5
@@ -990,6 +1116,8 @@ def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=
         CONV_TRACE.append(dict(B=B * D, Cin=Cin, Cout=wq.Cout, H=H, W=W, k=k, dil=dilation, bx3=True, fmt=wq.fmt, res=residual is not None,
                                n_out=int(raw) + int(want_act),
                                taps3d=wq.kk if vol else None, e0=e0, e1=e1))
+    tag_amax(out, slot_o)
+    tag_amax(out_act, slot_a)
     return (out, out_act) if want_act else out
 
 
@@ -1020,7 +1148,7 @@ def conv_wino_bx3_supported(Cin, Cout, H, W, dilation=1):
 
 
 def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dilation=1, pool2=False, want_stats=False,
-                    in_amax=None, out_scale=1.0):
+                    in_amax=None, out_scale=1.0, want_amax=False):
     """3x3 convolution through the split-bf16 Winograd kernel (same output options as conv2d).
     pool2: the ConvMeanPool form -- outputs (and the residual) are [B, Cout, H/2, W/2] 2x2 means of the convolution;
     raises IpdmUnsupported where the pooled epilogue is not built (small / odd images).
@@ -1035,8 +1163,13 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
     if bias_per_image and tuple(bias.shape) != (B, U.Cout):
         raise ValueError(f"conv2d_wino_bx3: per-image bias {tuple(bias.shape)} != {(B, U.Cout)}")
 
+    want_amax = bool(want_amax) and B <= 65535 and os.environ.get("IPDM_AMAX_PRODUCE", "1") != "0"
+    slot_o = amax_slot(B, x.device) if want_amax and raw else None
+    slot_a = amax_slot(B, x.device) if want_amax and act_out != ACT_NONE else None
+
     def ext_of(b0, b1):
-        return _conv_ext(U.fmt, None if amax_t is None else amax_t[b0:b1], x[b0:b1], False, bias_per_image, out_scale, U.Cout)
+        return _conv_ext(U.fmt, None if amax_t is None else amax_t[b0:b1], x[b0:b1], False, bias_per_image, out_scale, U.Cout,
+                         None if slot_o is None else slot_o[b0:b1], None if slot_a is None else slot_a[b0:b1])
 
     def bias_of(b0, b1):
         return bias[b0:b1] if bias_per_image else bias
@@ -1066,6 +1199,8 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
             e1.record()
             CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, fmt=U.fmt, res=residual is not None,
                                    n_out=int(raw) + int(want_act), pool2=False, ksplit=ksplit, e0=e0, e1=e1))
+        tag_amax(out, slot_o)
+        tag_amax(out_act, slot_a)
         return (out, out_act) if want_act else out
     part = None
     if want_stats and raw and USE_STATS_EPILOGUE and x.data_ptr() % 16 == 0:
@@ -1092,6 +1227,8 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
         e1.record()
         CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, fmt=U.fmt, res=residual is not None,
                                n_out=int(raw) + int(want_act), pool2=bool(pool2), e0=e0, e1=e1))
+    tag_amax(out, slot_o)
+    tag_amax(out_act, slot_a)
     return (out, out_act) if want_act else out
 
 

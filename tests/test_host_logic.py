@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ipdm.h but not exported by libipdm.so"
     assert sorted(_lib.SIGNATURES) == declared          # the ctypes table covers exactly the header
-    assert _lib.lib.ipdm_abi_version() == 3
+    assert _lib.lib.ipdm_abi_version() == 4
     assert _lib.lib.ipdm_build_arch() == b"gfx950"
 
 

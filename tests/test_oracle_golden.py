@@ -339,3 +339,19 @@ def test_oracle_fullsize_trajectory_vs_reference(golden, tag):
         assert metrics.nrmse(np.abs(x[b]), np.abs(ref[b])) < 1e-3
     np.testing.assert_allclose(x, ref, atol=1e-3 * np.abs(ref).max())
     assert np.linalg.norm((x - x0) - (ref - x0)) <= 2e-3 * np.linalg.norm(ref - x0)
+
+
+def test_temporal_score_network_oracle(golden):
+    """oracle/scorenet3d.py (NCSN3DShallow restated, ncsn3d.py:184-224) against the reference's own forward (g16); the
+    float64 evaluation of the same weights agrees with the fp32 one to fp32 rounding"""
+    from oracle import scorenet3d
+    g = golden("g16_ncsn3d")
+    sd = state_dict_from_golden(g, "net3d")
+    x, lab = torch.from_numpy(g["x"]), torch.from_numpy(g["labels"])
+    with torch.no_grad():
+        y = scorenet3d.ncsn3d_shallow(x, lab, sd)
+        y64 = scorenet3d.ncsn3d_shallow(x.double(), lab, {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()})
+    ref = torch.from_numpy(g["y"])
+    assert y.shape == ref.shape
+    assert float((y - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert float((y64.float() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
