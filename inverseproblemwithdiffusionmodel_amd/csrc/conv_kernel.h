@@ -189,12 +189,19 @@ struct ConvCfg {
   static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_ELEMS * sizeof(float);
 };
 
-// ELU without branches: exp(v) - 1 loses relative accuracy near 0, there a 4-term series is exact to 1e-7
+// ELU in the convolution epilogues, five instructions (v_mul, v_exp, v_add, v_cmp, v_cndmask): exp(v) - 1 is within ~1.2e-7
+// ABSOLUTE of expm1(v) everywhere (it loses RELATIVE accuracy for |v| << 1, where the value itself is negligible next to the
+// O(1) values it is summed with in the next convolution).  The 4-term series that round 1-3 selected for |v| < 1/16 cost seven
+// more VALU per value: ~900 issue cycles per wave and tile pass in the wide Winograd kernel (IPDM_ELU_SERIES restores it).
 __device__ __forceinline__ float fast_elu(float v) {
   const float e = __expf(v) - 1.f;
+#ifdef IPDM_ELU_SERIES
   const float p = v * (1.f + v * (0.5f + v * (0.16666667f + v * 0.041666668f)));
   const float neg = v > -0.0625f ? p : e;
   return v > 0.f ? v : neg;
+#else
+  return v > 0.f ? v : e;
+#endif
 }
 
 // Pipeline per workgroup (the wave hides its own latencies):

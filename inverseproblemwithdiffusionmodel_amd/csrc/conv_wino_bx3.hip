@@ -1287,6 +1287,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
         for (int rr = 0; rr < 16; ++rr) {
           const int col = (rr & 3) + 8 * (rr >> 2) + 4 * h;
           ms[((p0 + pi) * 32 + col) * 32 + j] = acc[pi][c][tg][rr];
+          acc[pi][c][tg][rr] = 0.f;                             // cleared for the next tile here, in the shadow of the exchange
         }
       IPDM_TE(1 + 4 * rnd);
       __syncthreads();
@@ -1452,7 +1453,6 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     ++tiles_done;
 #endif
     if (!has_next) break;
-    zero_acc();
     tile = next_tile;
     if (next_g.b != cur_g.b) hx_scales_of(next_g.b, hx_in, hx_out);
     cur_g = next_g;
