@@ -1,11 +1,15 @@
 """Undersampled-Fourier and multi-coil SENSE operators (mirror of the reference's
-``ncsn/linear_transforms/undersampling_fourier.py``: RandomUndersamplingFourier :39-97, SENSE :100-176).
+``ncsn/linear_transforms/undersampling_fourier.py``: UndersamplingFourier :10-36, RandomUndersamplingFourier :39-97,
+SENSE :100-176).
 
 Differences the reference forces on a drop-in, all explicit:
 * the checked-in ``_generate_mask`` ignores ``R`` and is hard-wired to T=24 / "R=16" parameters
   (:63-75).  Here ``mask_T`` selects the variant: ``mask_T=24`` reproduces the live code bit for bit,
   ``mask_T=1`` (default) is the single-frame variant the reference keeps commented out (:72-73) with the
   (sw, sm, sa) set looked up from ``R`` (``MASK_PARAMS``); ``mask_params=`` overrides the set.
+* ``mask_mode="uniform"`` is the LEGACY mask the reference keeps commented out (:50-61): ``rand(1, 1, W) <= 1 / R`` from torch's
+  generator plus a fully sampled centre window of ``int(W * center_lines_frac)`` lines -- the only mode in which ``R`` and
+  ``center_lines_frac`` act as the constructor's signature promises, for any R (bit-exact against tests/golden/g30).
 * coil maps are kept float64 on the host (``.sens_maps``, as the reference) and float32 on the device.
 """
 import warnings
@@ -14,6 +18,7 @@ import numpy as np
 import torch
 
 from . import LinearTransform, generate_mask, i2k_complex, k2i_complex, MASK_PARAMS
+from .masking import SkipLines
 from ... import ops
 
 
@@ -22,19 +27,55 @@ def _check_gpu(t, what):
         raise RuntimeError(f"{what}: expected a GPU tensor (no CPU fallback in this build)")
 
 
+class UndersamplingFourier(LinearTransform):
+    """every ``num_skip_lines``-th k-space ROW of the centred FFT (reference :10-36): S = P M F x, adjoint F^-1 M^T P^T"""
+
+    def __init__(self, num_skip_lines, in_shape):
+        self.skip_lines = SkipLines(num_skip_lines, in_shape)
+
+    def __call__(self, X: torch.Tensor) -> torch.Tensor:
+        _check_gpu(X, "UndersamplingFourier")
+        return self.skip_lines(i2k_complex(X.to(torch.complex64))).contiguous()
+
+    def conj_op(self, S: torch.Tensor) -> torch.Tensor:
+        _check_gpu(S, "UndersamplingFourier.conj_op")
+        return k2i_complex(self.skip_lines.conj_op(S.to(torch.complex64)))
+
+    def projection(self, X: torch.Tensor, S: torch.Tensor, lamda: float) -> torch.Tensor:
+        warnings.warn("Not used!")
+        return X
+
+
 class RandomUndersamplingFourier(LinearTransform):
-    def __init__(self, R, center_lines_frac, in_shape, seed=None, mask_T=1, mask_params=None):
-        """in_shape: (C, H, W)"""
+    def __init__(self, R, center_lines_frac, in_shape, seed=None, mask_T=1, mask_params=None, mask_mode="variable"):
+        """in_shape: (C, H, W); mask_mode "variable" (generate_mask, the live reference) or "uniform" (the legacy formula)"""
+        if mask_mode not in ("variable", "uniform"):
+            raise ValueError(f"mask_mode {mask_mode!r}: 'variable' or 'uniform'")
         self.R = R
         self.center_lines_frac = center_lines_frac
         self.in_shape = in_shape
         self.seed = seed
         self.mask_T = mask_T
         self.mask_params = mask_params
+        self.mask_mode = mask_mode
         self.mask = self._generate_mask()
         self._dev = {}
 
+    def _generate_uniform_mask(self):
+        """reference :50-61 (commented out there): float (1, 1, W), torch's default generator seeded with `seed`"""
+        torch.random.manual_seed(self.seed if self.seed is not None else torch.seed())
+        W = self.in_shape[-1]
+        mask = (torch.rand(1, 1, W) <= 1 / self.R).float()
+        win_size = int(W * self.center_lines_frac)
+        half_win_size = W // 2
+        start_idx = half_win_size - win_size // 2
+        end_idx = start_idx + win_size
+        mask[..., start_idx:end_idx] = 1.
+        return mask
+
     def _generate_mask(self):
+        if self.mask_mode == "uniform":
+            return self._generate_uniform_mask()
         torch.random.manual_seed(self.seed if self.seed is not None else torch.seed())
         W = self.in_shape[-1]
         if self.mask_params is not None:
@@ -44,7 +85,8 @@ class RandomUndersamplingFourier(LinearTransform):
         elif self.R in MASK_PARAMS:
             params = MASK_PARAMS[self.R]
         else:
-            raise ValueError(f"no variable-density mask parameters for R={self.R}; pass mask_params=dict(sw, sm, sa)")
+            raise ValueError(f"no variable-density mask parameters for R={self.R}; pass mask_params=dict(sw, sm, sa) or "
+                             "mask_mode='uniform' (the legacy rand <= 1/R mask, any R)")
         mask = generate_mask(self.mask_T, W, seed=self.seed, **params)
         return mask.unsqueeze(1)                          # (1, 1, W) or (T, 1, 1, W)
 
@@ -75,10 +117,11 @@ class RandomUndersamplingFourier(LinearTransform):
 
 
 class SENSE(LinearTransform):
-    def __init__(self, sens_type, num_sens, R, center_lines_frac, in_shape, seed, mask_T=1, mask_params=None):
+    def __init__(self, sens_type, num_sens, R, center_lines_frac, in_shape, seed, mask_T=1, mask_params=None,
+                 mask_mode="variable"):
         assert sens_type in ["exp"]
         self.random_under_fourier = RandomUndersamplingFourier(R, center_lines_frac, in_shape, seed, mask_T,
-                                                               mask_params)
+                                                               mask_params, mask_mode)
         maps = []
         for i in range(num_sens):
             s = self.random_under_fourier.seed

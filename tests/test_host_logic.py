@@ -323,3 +323,32 @@ def test_sample_grid_report_and_plot(tmp_path):
     curves, _ = vz.metric_vs_hyperparam([d], ["NRMSE"], ["lr_scaled"], {"lr_scaled": 1.0}, no_plot=True)
     assert curves[("lr_scaled", "NRMSE")][0].tolist() == [1.0]
 
+
+
+def test_legacy_uniform_mask_and_skip_lines_golden(golden):
+    """the legacy mask of RandomUndersamplingFourier (reference undersampling_fourier.py:50-61: rand(1, 1, W) <= 1 / R from torch's
+    generator + a fully sampled centre window of int(W * center_lines_frac) lines) bit for bit, and SkipLines (masking.py:6-44)
+    against the reference class's own outputs"""
+    from inverseproblemwithdiffusionmodel_amd.ncsn.linear_transforms.undersampling_fourier import RandomUndersamplingFourier
+    from inverseproblemwithdiffusionmodel_amd.ncsn.linear_transforms.masking import SkipLines
+    g = golden("g30_legacy_operators")
+    for i, (R, frac, W, seed) in enumerate(g["umask_cases"]):
+        op = RandomUndersamplingFourier(int(R), float(frac), (1, int(W), int(W)), seed=int(seed), mask_mode="uniform")
+        want = torch.from_numpy(g[f"umask_{i}"])
+        assert op.mask.dtype == torch.float32 and tuple(op.mask.shape) == (1, 1, int(W))
+        assert torch.equal(op.mask, want), (R, frac, W, seed)
+        win = int(W * frac)
+        assert op.mask[..., int(W) // 2 - win // 2: int(W) // 2 - win // 2 + win].all()          # the centre lines are kept
+    # an R without a variable-density parameter set raises in "variable" mode and names the way out
+    with pytest.raises(ValueError, match="uniform"):
+        RandomUndersamplingFourier(13, 0.04, (1, 32, 32), seed=0)
+    assert RandomUndersamplingFourier(13, 0.04, (1, 32, 32), seed=0, mask_mode="uniform").mask.shape[-1] == 32
+    x = torch.from_numpy(g["x"])
+    for n in (2, 3):
+        op = SkipLines(n, (1, 12, 10))
+        y = op(x)
+        assert torch.equal(y, torch.from_numpy(g[f"skip{n}_y"]))
+        assert torch.equal(op.conj_op(y), torch.from_numpy(g[f"skip{n}_adj"]))
+        proj = op.projection(x, torch.from_numpy(g[f"skip{n}_s"]), 0.3)
+        assert torch.allclose(proj, torch.from_numpy(g[f"skip{n}_proj"]), atol=1e-7)
+        assert torch.equal(x, torch.from_numpy(g["x"]))                                       # projection leaves its input alone

@@ -1248,3 +1248,33 @@ def test_conv_bx3_channel_tile_choice_keeps_the_bits(ops, fmt, dil):
         bigv = ops.conv3d(xv, pv)
         smallv = torch.cat([ops.conv3d(xv[i:i + 2].contiguous(), pv) for i in range(0, 64, 2)])
         assert torch.equal(bigv, smallv)
+
+
+def test_undersampling_fourier_and_uniform_mask_operators(ops, golden):
+    """UndersamplingFourier (reference undersampling_fourier.py:10-36) against the reference class's outputs, its adjointness, and
+    RandomUndersamplingFourier / SENSE built on the legacy uniform mask against the numpy oracle"""
+    from inverseproblemwithdiffusionmodel_amd.ncsn.linear_transforms.undersampling_fourier import (
+        UndersamplingFourier, RandomUndersamplingFourier, SENSE)
+    from oracle import kspace
+    g = golden("g30_legacy_operators")
+    x = torch.from_numpy(g["x"]).cuda()
+    for n in (2, 3):
+        op = UndersamplingFourier(n, (1, 12, 10))
+        y = op(x)
+        np.testing.assert_allclose(y.cpu().numpy(), g[f"uf{n}_y"], atol=2e-6)
+        np.testing.assert_allclose(op.conj_op(y).cpu().numpy(), g[f"uf{n}_adj"], atol=2e-6)
+        gen = torch.Generator().manual_seed(n)
+        s = torch.complex(torch.randn(y.shape, generator=gen), torch.randn(y.shape, generator=gen)).cuda()
+        lhs, rhs = torch.vdot(op(x).flatten(), s.flatten()), torch.vdot(x.flatten(), op.conj_op(s).flatten())
+        assert abs(lhs - rhs) <= 1e-5 * abs(lhs)
+    gen = torch.Generator().manual_seed(9)
+    img = torch.complex(torch.randn(3, 1, 64, 64, generator=gen), torch.randn(3, 1, 64, 64, generator=gen))
+    op = RandomUndersamplingFourier(6, 0.08, (1, 64, 64), seed=4, mask_mode="uniform")
+    m = op.mask.numpy().astype(bool)
+    want = kspace.fft2c(img.numpy()) * m
+    np.testing.assert_allclose(op(img.cuda()).cpu().numpy(), want, atol=3e-5)
+    sense = SENSE("exp", 4, 6, 0.08, (1, 64, 64), seed=4, mask_mode="uniform")
+    assert torch.equal(sense.random_under_fourier.mask, op.mask)
+    y = sense(img.cuda())
+    want = kspace.sense_forward(img.numpy(), sense.sens_maps.numpy(), m)
+    np.testing.assert_allclose(y.cpu().numpy(), want, atol=3e-5)
