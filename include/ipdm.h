@@ -33,6 +33,8 @@ extern "C" {
 #define IPDM_ACT_RELU 2
 #define IPDM_ACT_LRELU02 3
 #define IPDM_ACT_SWISH 4
+#define IPDM_ACT_COPY 5           /* identity, as an `act_out` code: "produce the second output without an activation" (with
+                                     ipdm_conv_ext_t.res_second: out = conv, out_act = conv + residual) */
 
 /* "maxima vectors": per-image max |x| of an activation tensor (or an upper bound of it), what the f16x2 convolutions take as
  * `in_amax` (dynamic range) and what producers hand over (`out_amax`, `act_amax`, `amax_out`, `amax_bound` below).  Layout:
@@ -340,6 +342,9 @@ typedef struct {
   const float* in_amax;
   int bias_bstride;
   float out_scale;
+  int res_second;    /* != 0: the residual enters the SECOND output only -- out = (conv + bias) * out_scale, out_act =          */
+                     /* act_out((conv + bias + residual) * out_scale).  CRPBlock's `path = conv(pool(path)); x = path + x`          */
+                     /* (ncsn/models/layers.py:76-83) as one launch: `path` and the running sum leave the same epilogue           */
   float* out_amax;   /* maxima vector ZEROED by the caller, or NULL: per-image max |out| of what the call stores, accumulated with  */
   float* act_amax;   /* atomic max (exact, order-independent) -- likewise for out_act.  What the NEXT f16x2 convolution takes as   */
                      /* in_amax: the dynamic range then costs no pass over the tensor (the reference has no counterpart: fp32)      */

@@ -16,8 +16,8 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 class ConvExt(ctypes.Structure):
     """ipdm_conv_ext_t (include/ipdm.h): optional extras of the split-operand convolution calls"""
-    _fields_ = [("in_amax", c_void_p), ("bias_bstride", c_int), ("out_scale", c_float), ("out_amax", c_void_p),
-                ("act_amax", c_void_p)]
+    _fields_ = [("in_amax", c_void_p), ("bias_bstride", c_int), ("out_scale", c_float), ("res_second", c_int),
+                ("out_amax", c_void_p), ("act_amax", c_void_p)]
 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -428,10 +428,13 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
             continue;
           }
           if (has_bias) v += bv[m][r];
-          if (has_res) v += rv[q & 1][r];
+          float vr = v;                                       // what `out` stores: without the residual when it is the second
+          if (has_res) v += rv[q & 1][r];                     // output's alone (a.res_second)
+          vr = a.res_second ? vr : v;
           v *= a.out_scale;
-          amx_o = fmaxf(amx_o, fabsf(v));
-          if (a.out) a.out[o] = v;
+          vr *= a.out_scale;
+          amx_o = fmaxf(amx_o, fabsf(vr));
+          if (a.out) a.out[o] = vr;
           if (a.out_act) {
             const float e = a.act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, a.act_out);
             amx_a = fmaxf(amx_a, fabsf(e));
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(256) void bx3_splitk_reduce_kernel(const float* __r
                                                                 const float* __restrict__ residual, float* out,
                                                                 float* out_act, int act_out, int Cout, int64_t plane,
                                                                 int64_t total, int bias_bstride, float out_scale,
-                                                                float* amax_out, float* amax_act) {
+                                                                float* amax_out, float* amax_act, int res_second) {
   // grid = (blocks per image, images) when the maxima are wanted (a workgroup then stays inside one image), else 1-D grid-stride
   const int64_t per_image = plane * Cout;
   const bool by_image = gridDim.y > 1 || amax_out || amax_act;      // (launchers: B <= 65535 whenever the maxima are wanted)
@@ -538,10 +541,13 @@ __global__ __launch_bounds__(256) void bx3_splitk_reduce_kernel(const float* __r
     float v = partial[i];
     for (int s = 1; s < ksplit; ++s) v += partial[(size_t)s * total + i];
     if (bias) v += bias[(i / per_image) * bias_bstride + (i / plane) % Cout];
+    float vr = v;
     if (residual) v += residual[i];
+    vr = res_second ? vr : v;
     v *= out_scale;
-    amx_o = fmaxf(amx_o, fabsf(v));
-    if (out) out[i] = v;
+    vr *= out_scale;
+    amx_o = fmaxf(amx_o, fabsf(vr));
+    if (out) out[i] = vr;
     if (out_act) {
       const float e = act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, act_out);
       amx_a = fmaxf(amx_a, fabsf(e));
@@ -740,7 +746,7 @@ static int conv_bx3_splitk_entry(const float* x, const void* wq, const float* bi
   const int64_t plane = (int64_t)D * H * W, total = (int64_t)B * Cout * plane;
   hipLaunchKernelGGL(bx3_splitk_reduce_kernel, splitk_reduce_grid(B, Cout * plane, amax_out || amax_act), dim3(256), 0,
                      ipdm_stream(stream), work, ksplit, bias, residual, out, out_act, act_out, Cout, (long long)plane,
-                     (long long)total, a.bias_bstride, a.out_scale, amax_out, amax_act);
+                     (long long)total, a.bias_bstride, a.out_scale, amax_out, amax_act, a.res_second);
   return ipdm_launch_status();
 }
 

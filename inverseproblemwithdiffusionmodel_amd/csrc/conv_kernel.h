@@ -126,6 +126,7 @@ struct ConvArgs {
   float out_scale = 1.f;     //   ... and result = (conv + bias + residual) * out_scale (score_sde skip_rescale: 1 / sqrt 2)
   const float* in_amax = nullptr;   // f16x2 only: maxima vector of the input ([B][IPDM_AMAX_SLOT], ipdm.h) -> per-image power-of-two
                                     //   input scale (hx_dynamic_scale(ipdm_amax_read(.))); NULL: static range contract |x| < 65504
+  int res_second = 0;        // split-operand kernels: the residual enters out_act only (out = conv + bias; ipdm_conv_ext_t)
   float* amax_out = nullptr; // split-operand kernels: maxima vectors ([B][IPDM_AMAX_SLOT], zeroed by the caller) of out / out_act: max
   float* amax_act = nullptr; //   |stored value| per image, one atomic max per wave (ipdm_common.h) -- the NEXT convolution's in_amax
   int hx = 0;                // conv_bx3 / conv_wino_bx3: 1 = the weights are an f16x2 blob (two fp16 pieces + per-channel inverse
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void bx3_splitk_reduce_kernel(const float* __r
                                                                 const float* __restrict__ residual, float* out,
                                                                 float* out_act, int act_out, int Cout, int64_t plane,
                                                                 int64_t total, int bias_bstride, float out_scale,
-                                                                float* amax_out, float* amax_act);
+                                                                float* amax_out, float* amax_act, int res_second);
 
 // its grid: 1-D grid-stride, or (blocks per image, images) when per-image maxima are wanted
 inline dim3 splitk_reduce_grid(int B, int64_t per_image, bool by_image) {
@@ -157,6 +158,7 @@ inline void conv_apply_ext(ConvArgs& a, const ipdm_conv_ext_t* ext, int hx) {
   a.in_amax = hx && ext ? ext->in_amax : nullptr;
   a.bias_bstride = ext ? ext->bias_bstride : 0;
   a.out_scale = ext && ext->out_scale != 0.f ? ext->out_scale : 1.f;
+  a.res_second = ext ? (ext->res_second != 0) : 0;
   a.amax_out = ext ? ext->out_amax : nullptr;
   a.amax_act = ext ? ext->act_amax : nullptr;
 }

@@ -536,17 +536,22 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
             y1v += bias;
           }
           const size_t o = ((size_t)b * a.Cout + co) * HW + (size_t)(oy + (SMALL ? d * ii : ii)) * a.W + ox;
+          float r0v = y0v, r1v = y1v;                         // what `out` stores (a.res_second: without the residual)
           if (has_res) {
             y0v += rv[c][i][ii].x;
             y1v += rv[c][i][ii].y;
           }
+          r0v = a.res_second ? r0v : y0v;
+          r1v = a.res_second ? r1v : y1v;
           y0v *= a.out_scale;
           y1v *= a.out_scale;
-          amx_o = fmaxf(amx_o, fmaxf(fabsf(y0v), fabsf(y1v)));
+          r0v *= a.out_scale;
+          r1v *= a.out_scale;
+          amx_o = fmaxf(amx_o, fmaxf(fabsf(r0v), fabsf(r1v)));
           if constexpr (SMALL) {
             if (a.out) {
-              a.out[o] = y0v;
-              a.out[o + d] = y1v;
+              a.out[o] = r0v;
+              a.out[o + d] = r1v;
             }
             if (a.out_act) {
               const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
               a.out_act[o + d] = e1;
             }
           } else {
-            if (a.out) *reinterpret_cast<float2*>(a.out + o) = make_float2(y0v, y1v);
+            if (a.out) *reinterpret_cast<float2*>(a.out + o) = make_float2(r0v, r1v);
             if (a.out_act) {
               const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
               const float e1 = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
@@ -1336,11 +1341,14 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
             }
             float v = (((y00 + y10) + y01) + y11) * 0.25f;
             const unsigned ob = boff(c, tg, i, 0);
+            float vr = v;                                       // what `out` stores (a.res_second: without the residual)
             if (has_res) v += resv[bf][i][0].x;
+            vr = a.res_second ? vr : v;
             v *= a.out_scale;
-            if constexpr (STATS) sv[i][0] = v;
-            if constexpr (!KSP) amx_o = fmaxf(amx_o, fabsf(v));
-            if (a.out) *reinterpret_cast<float*>(out_b + ob) = v;
+            vr *= a.out_scale;
+            if constexpr (STATS) sv[i][0] = vr;
+            if constexpr (!KSP) amx_o = fmaxf(amx_o, fabsf(vr));
+            if (a.out) *reinterpret_cast<float*>(out_b + ob) = vr;
             if (a.out_act) {
               const float e = a.act_out == IPDM_ACT_ELU ? fast_elu(v) : ipdm_act(v, a.act_out);
               if constexpr (!KSP) amx_a = fmaxf(amx_a, fabsf(e));
@@ -1361,26 +1369,31 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
             [[maybe_unused]] unsigned ob = 0;
             if constexpr (POLY) o = out_index(c, tg, i, ii);
             else ob = boff(c, tg, i, ii);
+            float r0v = y0v, r1v = y1v;                       // what `out` stores (a.res_second: without the residual)
             if (has_res) {
               y0v += resv[bf][i][ii].x;
               y1v += resv[bf][i][ii].y;
             }
+            r0v = a.res_second ? r0v : y0v;
+            r1v = a.res_second ? r1v : y1v;
             y0v *= a.out_scale;
             y1v *= a.out_scale;
+            r0v *= a.out_scale;
+            r1v *= a.out_scale;
             if constexpr (STATS) {
-              sv[i][2 * ii] = y0v;
-              sv[i][2 * ii + 1] = y1v;
+              sv[i][2 * ii] = r0v;
+              sv[i][2 * ii + 1] = r1v;
             }
-            if constexpr (!KSP) amx_o = fmaxf(amx_o, fmaxf(fabsf(y0v), fabsf(y1v)));
+            if constexpr (!KSP) amx_o = fmaxf(amx_o, fmaxf(fabsf(r0v), fabsf(r1v)));
             if constexpr (POLY) {
               if (a.out) {
-                a.out[o] = y0v;
-                a.out[o + pd] = y1v;
+                a.out[o] = r0v;
+                a.out[o + pd] = r1v;
               }
             } else {
               // (streaming stores: the result is read next by another kernel after 200+ MB of other traffic; `nt` measured -0.6 % per step)
               typedef float ntf2 __attribute__((ext_vector_type(2)));
-              if (a.out) __builtin_nontemporal_store(ntf2{y0v, y1v}, reinterpret_cast<ntf2*>(out_b + ob));
+              if (a.out) __builtin_nontemporal_store(ntf2{r0v, r1v}, reinterpret_cast<ntf2*>(out_b + ob));
             }
             if (a.out_act) {
               const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
@@ -1669,6 +1682,8 @@ static int conv_wino_bx3_launch_ksplit_t(ConvArgs a, int ksplit, float* work, hi
   float* const amax_out = a.amax_out;
   float* const amax_act = a.amax_act;
   a.amax_out = a.amax_act = nullptr;              // the parts are partial sums: the maxima belong to the reduce pass
+  const int res_second = a.res_second;
+  a.res_second = 0;
   const float out_scale = a.out_scale;
   a.out_scale = 1.f;                              // the parts are raw sums: bias / residual / scale belong to the reduce pass
   const int64_t nblk = (int64_t)a.B * a.tiles_x * a.tiles_y * a.co_tiles * ksplit;
@@ -1685,7 +1700,7 @@ static int conv_wino_bx3_launch_ksplit_t(ConvArgs a, int ksplit, float* work, hi
                      X_LDS_BYTES, s, a, (int)nblk);
   const int64_t plane = (int64_t)a.H * a.W, total = (int64_t)a.B * a.Cout * plane;
   hipLaunchKernelGGL(bx3_splitk_reduce_kernel, splitk_reduce_grid(a.B, (int64_t)a.Cout * plane, amax_out || amax_act), dim3(256), 0, s, work, ksplit, bias, residual,
-                     out, out_act, a.act_out, a.Cout, plane, total, a.bias_bstride, out_scale, amax_out, amax_act);
+                     out, out_act, a.act_out, a.Cout, plane, total, a.bias_bstride, out_scale, amax_out, amax_act, res_second);
   return ipdm_launch_status();
 }
 

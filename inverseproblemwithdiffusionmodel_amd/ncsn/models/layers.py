@@ -89,7 +89,7 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
         return self._cached("direct_" + ops.CONV_IMPL, ops.conv_weight)
 
     def forward(self, x, coef=None, act=ops.ACT_NONE, residual=None, out=None, act_out=ops.ACT_NONE, raw=True,
-                want_stats=False, in_amax=None, feeds_conv=True):
+                want_stats=False, in_amax=None, feeds_conv=True, res_second=False):
         """want_stats: the result goes into an InstanceNorm++ next (the Winograd kernel's statistics epilogue then spares
         that normalisation its pass over the tensor; ignored by the other kernels).
         f16x2 family: the input's per-image maxima come with the tensor from its producer (ops.in_amax_for; `in_amax` overrides)
@@ -116,12 +116,13 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
                 and act == ops.ACT_NONE and out is None and ops.wino_bx3_pays(self.in_planes, self.out_planes, x.shape[2],
                                                                               x.shape[3], self.dilation)):
             return ops.conv2d_wino_bx3(x, self.packed_wino_bx3(), bias, residual, act_out=act_out, raw=raw,
-                                       dilation=self.dilation, want_stats=want_stats, in_amax=in_amax, want_amax=produce)
+                                       dilation=self.dilation, want_stats=want_stats, in_amax=in_amax, want_amax=produce,
+                                       res_second=res_second)
         if self.ndim == 3:
             return ops.conv3d(x, self.packed(), bias, coef, act, residual, self.dilation, act_out=act_out, raw=raw,
-                              in_amax=in_amax, want_amax=produce)
+                              in_amax=in_amax, want_amax=produce, res_second=res_second)
         return ops.conv2d(x, self.packed(), bias, coef, act, residual, self.dilation, out=out, act_out=act_out, raw=raw,
-                          in_amax=in_amax, want_amax=produce)
+                          in_amax=in_amax, want_amax=produce, res_second=res_second)
 
 
 def conv1x1(in_planes, out_planes, stride=1, bias=True, spec_norm=False, ndim=2):
@@ -198,6 +199,8 @@ class CRPBlock(nn.Module):
                     x, out_act = self.convs[i](pooled, residual=x, act_out=code)
                 else:
                     x = self.convs[i](pooled, residual=x)
+            elif ops.split_impl():                           # path = conv(pool(path)); x = path + x: both leave ONE epilogue
+                path, x = self.convs[i](pooled, residual=x, res_second=True, act_out=ops.ACT_COPY)
             else:
                 path = self.convs[i](pooled)
                 x = ops.add(path, x)

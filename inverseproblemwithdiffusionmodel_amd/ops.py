@@ -12,6 +12,7 @@ from . import _lib
 from ._lib import call, P
 
 ACT_NONE, ACT_ELU, ACT_RELU, ACT_LRELU02, ACT_SWISH = 0, 1, 2, 3, 4
+ACT_COPY = 5          # identity as an `act_out` code: "produce the second output, unactivated" (with res_second: conv + residual)
 CONV_TRACE = None     # set to a list by engine.conv_census(): per-launch shapes + HIP events
 
 ACT_CODES = {"none": ACT_NONE, None: ACT_NONE, "elu": ACT_ELU, "relu": ACT_RELU, "lrelu": ACT_LRELU02,
@@ -802,11 +803,13 @@ def conv2d_wino(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dila
 
 
 def conv3d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, act_out=ACT_NONE, raw=True, in_amax=None,
-           want_amax=False):
+           want_amax=False, res_second=False):
     """x [B,Cin,D,H,W]; wt packed [27 or 1, Cin, Cout]; same fused input/output options as conv2d"""
     if isinstance(wt, PackedBx3):
         return conv_bx3(x, wt, bias, coef, act, residual, dilation, act_out=act_out, raw=raw, in_amax=in_amax,
-                        want_amax=want_amax)
+                        want_amax=want_amax, res_second=res_second)
+    if res_second:
+        raise _lib.IpdmUnsupported("conv3d: res_second exists on the split-operand kernels only")
     x = _gpu(x, torch.float32, "x")
     B, Cin, D, H, W = x.shape
     kk, Cin_w, Cout = wt.shape
@@ -847,7 +850,7 @@ def temporal_taps(x, mode):
 
 
 def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, pool2=False, out=None,
-           act_out=ACT_NONE, raw=True, in_amax=None, out_scale=1.0, want_amax=False):
+           act_out=ACT_NONE, raw=True, in_amax=None, out_scale=1.0, want_amax=False, res_second=False):
     """x [B,Cin,H,W]; wt packed [k*k,Cin,Cout].  Input side: optional InstanceNorm++ coefficients / activation.
     Output side: bias, residual add; act_out != NONE additionally returns the activated copy act_out(result)
     (raw=False: ONLY the activated copy is produced).  Returns out, or (out, out_act) when act_out is set
@@ -856,8 +859,8 @@ def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1,
         if pool2:
             raise _lib.IpdmUnsupported("conv2d: pool2 epilogue is not fused")
         return conv_bx3(x, wt, bias, coef, act, residual, dilation, out=out, act_out=act_out, raw=raw, in_amax=in_amax,
-                        out_scale=out_scale, want_amax=want_amax)
-    if out_scale != 1.0 or (bias is not None and bias.dim() == 2):
+                        out_scale=out_scale, want_amax=want_amax, res_second=res_second)
+    if out_scale != 1.0 or (bias is not None and bias.dim() == 2) or res_second:
         raise _lib.IpdmUnsupported("conv2d: per-image bias / out_scale exist on the split-operand kernels only")
     x = _gpu(x, torch.float32, "x")
     B, Cin, H, W = x.shape
@@ -1011,11 +1014,13 @@ def absmax_per_image(x):
     return out
 
 
-def _conv_ext(fmt, in_amax, x, fused_input, bias_per_image=False, out_scale=1.0, Cout=0, out_amax=None, act_amax=None):
+def _conv_ext(fmt, in_amax, x, fused_input, bias_per_image=False, out_scale=1.0, Cout=0, out_amax=None, act_amax=None,
+              res_second=False):
     """-> the `ext` argument of the split-operand entry points (NULL when every extra is at its default).
     in_amax (hx2 blobs only): None -> static range contract; True -> measure the input here; a tensor -> as given (a fused input
     normalisation / activation makes the raw maximum meaningless: ignored).  bias_per_image: bias is [B, Cout].  out_scale:
-    result = (conv + bias + residual) * out_scale.  out_amax / act_amax: zeroed [B] slots for the maxima of what is stored."""
+    result = (conv + bias + residual) * out_scale.  out_amax / act_amax: zeroed maxima vectors for what is stored.  res_second:
+    the residual enters the second output only (out = conv + bias, out_act = act_out(conv + bias + residual))."""
     amax_ptr = None
     if fmt == "hx2" and in_amax is not None and not fused_input:
         if in_amax is True:
@@ -1026,9 +1031,10 @@ def _conv_ext(fmt, in_amax, x, fused_input, bias_per_image=False, out_scale=1.0,
                              "(ops.absmax_per_image / a producer's tag)")
         amax_ptr = in_amax.data_ptr()
         _KEEP.append(in_amax)                    # (the kernel reads it asynchronously: keep the tensor alive until the call returns)
-    if amax_ptr is None and not bias_per_image and out_scale == 1.0 and out_amax is None and act_amax is None:
+    if (amax_ptr is None and not bias_per_image and out_scale == 1.0 and out_amax is None and act_amax is None
+            and not res_second):
         return P(0)
-    ext = _lib.ConvExt(amax_ptr, int(Cout) if bias_per_image else 0, float(out_scale),
+    ext = _lib.ConvExt(amax_ptr, int(Cout) if bias_per_image else 0, float(out_scale), int(bool(res_second)),
                        None if out_amax is None else out_amax.data_ptr(), None if act_amax is None else act_amax.data_ptr())
     _KEEP.append(ext)
     del _KEEP[:-8]
@@ -1064,8 +1070,9 @@ def conv_bx3_weight(w, fmt="bx3"):
 
 
 def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, out=None, act_out=ACT_NONE, raw=True,
-             in_amax=None, out_scale=1.0, want_amax=False):
+             in_amax=None, out_scale=1.0, want_amax=False, res_second=False):
     """2-D ([B,Cin,H,W]) or 3-D ([B,Cin,D,H,W]) convolution, same options / return convention as conv2d / conv3d.
+    res_second (needs residual, act_out (ACT_COPY = none) and raw): -> (conv + bias, act_out(conv + bias + residual)).
     in_amax (hx2 blobs only): None = static range contract |x| < 65504, True = measure the input (ipdm_absmax_f32) and scale every
     image into fp16's range, or the per-image maxima themselves"""
     x = _gpu(x, torch.float32, "x")
@@ -1076,7 +1083,10 @@ def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=
     want_amax = bool(want_amax) and x.shape[0] <= 65535 and os.environ.get("IPDM_AMAX_PRODUCE", "1") != "0"
     slot_o = amax_slot(x.shape[0], x.device) if want_amax and raw else None
     slot_a = amax_slot(x.shape[0], x.device) if want_amax and want_act else None
-    ext = _conv_ext(wq.fmt, in_amax, x, coef is not None or act != ACT_NONE, bias_per_image, out_scale, wq.Cout, slot_o, slot_a)
+    if res_second and (residual is None or not want_act or not raw):
+        raise ValueError("conv_bx3: res_second needs a residual and both outputs (act_out, e.g. ACT_COPY; raw=True)")
+    ext = _conv_ext(wq.fmt, in_amax, x, coef is not None or act != ACT_NONE, bias_per_image, out_scale, wq.Cout, slot_o, slot_a,
+                    res_second)
     if wq.Cin != x.shape[1]:
         raise ValueError(f"conv_bx3: weight Cin {wq.Cin} != input Cin {x.shape[1]}")
     vol = x.dim() == 5
@@ -1148,8 +1158,9 @@ def conv_wino_bx3_supported(Cin, Cout, H, W, dilation=1):
 
 
 def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dilation=1, pool2=False, want_stats=False,
-                    in_amax=None, out_scale=1.0, want_amax=False):
+                    in_amax=None, out_scale=1.0, want_amax=False, res_second=False):
     """3x3 convolution through the split-bf16 Winograd kernel (same output options as conv2d).
+    res_second (needs residual, act_out (ACT_COPY = none) and raw): -> (conv + bias, act_out(conv + bias + residual)).
     pool2: the ConvMeanPool form -- outputs (and the residual) are [B, Cout, H/2, W/2] 2x2 means of the convolution;
     raises IpdmUnsupported where the pooled epilogue is not built (small / odd images).
     want_stats: the result feeds an InstanceNorm++ -- where the statistics epilogue exists for this shape, its partials
@@ -1169,12 +1180,14 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
 
     def ext_of(b0, b1):
         return _conv_ext(U.fmt, None if amax_t is None else amax_t[b0:b1], x[b0:b1], False, bias_per_image, out_scale, U.Cout,
-                         None if slot_o is None else slot_o[b0:b1], None if slot_a is None else slot_a[b0:b1])
+                         None if slot_o is None else slot_o[b0:b1], None if slot_a is None else slot_a[b0:b1], res_second)
 
     def bias_of(b0, b1):
         return bias[b0:b1] if bias_per_image else bias
     if U.kk != 16 or U.Cin != Cin:
         raise ValueError("conv2d_wino_bx3: weight blob does not match the input")
+    if res_second and (residual is None or act_out == ACT_NONE or not raw):
+        raise ValueError("conv2d_wino_bx3: res_second needs a residual and both outputs (act_out, e.g. ACT_COPY; raw=True)")
     Cout = U.Cout
     want_act = act_out != ACT_NONE
     oh, ow = (H // 2, W // 2) if pool2 else (H, W)

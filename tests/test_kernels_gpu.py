@@ -1278,3 +1278,41 @@ def test_undersampling_fourier_and_uniform_mask_operators(ops, golden):
     y = sense(img.cuda())
     want = kspace.sense_forward(img.numpy(), sense.sens_maps.numpy(), m)
     np.testing.assert_allclose(y.cpu().numpy(), want, atol=3e-5)
+
+
+@pytest.mark.parametrize("fmt", ["hx2", "bx3"])
+def test_residual_into_the_second_output_only(ops, fmt):
+    """res_second: out = conv + bias, out_act = act_out(conv + bias + residual) from ONE launch -- CRPBlock's
+    `path = conv(pool(path)); x = path + x` (reference ncsn/models/layers.py:76-83) without the separate add; every epilogue
+    that a CRP convolution can meet (wide / small / split-K Winograd, direct 2-D and 3-D), bits equal to the two-launch form"""
+    gen = torch.Generator().manual_seed(61)
+    for (B, Cin, Cout, H, W, kind) in [(2, 64, 64, 32, 64, "wino"), (3, 64, 64, 16, 16, "wino"), (3, 256, 256, 16, 16, "wino"),
+                                       (2, 32, 48, 20, 24, "direct"), (1, 256, 64, 8, 16, "direct")]:
+        x = torch.randn(B, Cin, H, W, generator=gen).cuda()
+        w = (torch.randn(Cout, Cin, 3, 3, generator=gen) / (9 * Cin) ** 0.5).cuda()
+        res = torch.randn(B, Cout, H, W, generator=gen).cuda()
+        if kind == "wino":
+            U = ops.conv_wino_bx3_weight(w, fmt=fmt)
+            path, xs = ops.conv2d_wino_bx3(x, U, None, res, act_out=ops.ACT_COPY, res_second=True, want_amax=True)
+            path2 = ops.conv2d_wino_bx3(x, U)
+            both = ops.conv2d_wino_bx3(x, U, None, res)
+            _, act = ops.conv2d_wino_bx3(x, U, None, res, act_out=ops.ACT_ELU, res_second=True)
+        else:
+            wq = ops.conv_bx3_weight(w, fmt=fmt)
+            path, xs = ops.conv_bx3(x, wq, residual=res, act_out=ops.ACT_COPY, res_second=True, want_amax=True)
+            path2 = ops.conv_bx3(x, wq)
+            both = ops.conv_bx3(x, wq, residual=res)
+            _, act = ops.conv_bx3(x, wq, residual=res, act_out=ops.ACT_ELU, res_second=True)
+        assert torch.equal(path, path2) and torch.equal(xs, both), (kind, Cin, H)
+        assert torch.equal(xs, ops.add(path, res))                      # == the separate add kernel
+        assert (act - F.elu(both)).abs().max() < 4e-6
+        assert torch.equal(ops.amax_value(ops.amax_of(path)), path.abs().amax(dim=(1, 2, 3)))
+        assert torch.equal(ops.amax_value(ops.amax_of(xs)), xs.abs().amax(dim=(1, 2, 3)))
+    x3 = torch.randn(2, 16, 4, 8, 12, generator=gen).cuda()
+    w3 = (torch.randn(32, 16, 3, 3, 3, generator=gen) / (27 * 16) ** 0.5).cuda()
+    r3 = torch.randn(2, 32, 4, 8, 12, generator=gen).cuda()
+    wq3 = ops.conv_bx3_weight(w3, fmt=fmt)
+    p3, s3 = ops.conv3d(x3, wq3, residual=r3, act_out=ops.ACT_COPY, res_second=True)
+    assert torch.equal(p3, ops.conv3d(x3, wq3)) and torch.equal(s3, ops.conv3d(x3, wq3, residual=r3))
+    with pytest.raises(ValueError):
+        ops.conv_bx3(x3, wq3, act_out=ops.ACT_COPY, res_second=True)      # no residual
