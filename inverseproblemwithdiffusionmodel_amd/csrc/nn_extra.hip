@@ -117,6 +117,64 @@ __global__ __launch_bounds__(T) void gn_plane_kernel(const float* __restrict__ x
   }
 }
 
+// Whole GROUPS of up to 65536 elements (every level of NCSN++ below the full resolution): the cpg planes of a group are
+// contiguous in NCHW, so the group is ONE register-resident block -- mean and variance in two in-register sweeps exactly as the
+// definition reads, and the workgroup writes the coefficients of its cpg channels itself: one launch instead of plane + combine
+// (round 3: 109 gn_combine launches of 4.8 us per NCSN++ forward).  Two sources (x1 holds channels [0, C1), x2 the rest of the
+// virtual concatenation; C1 a multiple of the group's channel count, so a group never straddles them; x2 == NULL: one source).
+template <int T>
+__global__ __launch_bounds__(T) void gn_group_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2,
+                                                     const float* __restrict__ weight, const float* __restrict__ bias,
+                                                     float* __restrict__ coef, int HW, int G, float eps) {
+  __shared__ double red[T / 64];
+  const int C = C1 + C2, cpg = C / G;
+  const int b = blockIdx.x / G, g = blockIdx.x % G;
+  const int c0 = g * cpg;
+  const float* p = c0 < C1 ? x1 + ((size_t)b * C1 + c0) * HW : x2 + ((size_t)b * C2 + (c0 - C1)) * HW;
+  const int n = cpg * HW, n4 = n / 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float4 keep[16];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = tid + k * T;
+    keep[k] = i < n4 ? reinterpret_cast<const float4*>(p)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (tid + k * T < n4) s += (keep[k].x + keep[k].y) + (keep[k].z + keep[k].w);
+  double ds = ipdm_wave_sum((double)s);
+  if (lane == 0) red[wave] = ds;
+  __syncthreads();
+  double tot = 0.0;
+#pragma unroll
+  for (int w = 0; w < T / 64; ++w) tot += red[w];
+  const float mean = (float)(tot / (double)n);
+  __syncthreads();
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (tid + k * T < n4) {
+      const float a = keep[k].x - mean, bb = keep[k].y - mean, c = keep[k].z - mean, d = keep[k].w - mean;
+      q += (a * a + bb * bb) + (c * c + d * d);
+    }
+  }
+  double dq = ipdm_wave_sum((double)q);
+  if (lane == 0) red[wave] = dq;
+  __syncthreads();
+  double m2 = 0.0;
+#pragma unroll
+  for (int w = 0; w < T / 64; ++w) m2 += red[w];
+  const float rstd = 1.0f / sqrtf((float)(m2 / (double)n) + eps);
+  for (int c = tid; c < cpg; c += T) {
+    const int ch = c0 + c;
+    float* o = coef + ((size_t)b * C + ch) * 3;
+    o[0] = mean;
+    o[1] = (weight ? weight[ch] : 1.f) * rstd;
+    o[2] = bias ? bias[ch] : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(64) void gn_combine_kernel(const float* __restrict__ weight, const float* __restrict__ bias,
                                                         float* __restrict__ coef, int C, int HW, int G, float eps) {
   const int b = blockIdx.x / G, g = blockIdx.x % G;
@@ -278,6 +336,16 @@ extern "C" int ipdm_groupnorm_coef_f32(const float* x, const float* weight, cons
   IPDM_REQUIRE(B >= 0 && C > 0 && HW > 0 && G > 0 && C % G == 0);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && coef);
+  const int64_t gn = (int64_t)(C / G) * HW;                   // elements of a group
+  if (!plane_amax && gn % 4 == 0 && gn <= 65536 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    if (gn <= 16384)
+      hipLaunchKernelGGL(gn_group_kernel<256>, dim3(B * G), dim3(256), 0, ipdm_stream(stream), x, C, nullptr, 0, weight, bias, coef,
+                         HW, G, eps);
+    else
+      hipLaunchKernelGGL(gn_group_kernel<1024>, dim3(B * G), dim3(1024), 0, ipdm_stream(stream), x, C, nullptr, 0, weight, bias,
+                         coef, HW, G, eps);
+    return ipdm_launch_status();
+  }
   if (HW % 4 == 0 && HW <= 65536 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     if (HW <= 16384)
       hipLaunchKernelGGL(gn_plane_kernel<256>, dim3(B * C), dim3(256), 0, ipdm_stream(stream), x, coef, HW, C, C, 0, plane_amax);
@@ -304,6 +372,15 @@ extern "C" int ipdm_groupnorm_coef_cat_f32(const float* x1, int C1, const float*
   if (!(HW % 4 == 0 && HW <= 65536 && ((reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(x2)) & 15) == 0))
     return IPDM_EUNSUPPORTED;
   hipStream_t s = ipdm_stream(stream);
+  const int cpg = C / G;
+  const int64_t gn = (int64_t)cpg * HW;
+  if (!plane_amax && C1 % cpg == 0 && gn <= 65536) {           // whole groups in registers: one launch
+    if (gn <= 16384)
+      hipLaunchKernelGGL(gn_group_kernel<256>, dim3(B * G), dim3(256), 0, s, x1, C1, x2, C2, weight, bias, coef, HW, G, eps);
+    else
+      hipLaunchKernelGGL(gn_group_kernel<1024>, dim3(B * G), dim3(1024), 0, s, x1, C1, x2, C2, weight, bias, coef, HW, G, eps);
+    return ipdm_launch_status();
+  }
   if (HW <= 16384) {
     hipLaunchKernelGGL(gn_plane_kernel<256>, dim3(B * C1), dim3(256), 0, s, x1, coef, HW, C1, C, 0, plane_amax);
     hipLaunchKernelGGL(gn_plane_kernel<256>, dim3(B * C2), dim3(256), 0, s, x2, coef, HW, C2, C, C1, plane_amax);

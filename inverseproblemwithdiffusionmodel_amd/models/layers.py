@@ -56,15 +56,20 @@ class Conv(ops.PackedWeightMixin, nn.Module):
         impl = ops.impl_unbounded()
         return self._cache.get(self.weight, "wino_" + impl, lambda w: ops.conv_wino_split_weight(w, impl))
 
-    def forward(self, x, residual=None, bounded=False, bias_rows=None, out_scale=1.0, in_amax=None):
+    def forward(self, x, residual=None, bounded=False, bias_rows=None, out_scale=1.0, in_amax=None, feeds_conv=False):
         """bounded: x is act(GroupNorm(.)) (possibly FIR-resampled) -- |x| <= |gamma| sqrt(group size) + |beta|, inside the
-        f16x2 family's static range; otherwise (raw skip / pyramid / input streams) the convolution measures its input and
-        runs with the dynamic range (ops.unbounded_amax).
+        f16x2 family's static range; otherwise (raw skip / pyramid / input streams) the convolution runs with the dynamic
+        range: the per-image maxima ride on the tensor from its producer (ops.in_amax_for: a convolution epilogue, a FIR
+        resampler passing its input's bound on) or are measured once and attached.
+        feeds_conv: a convolution reads this layer's RESULT raw (a block's output: the next shortcut / the skip connection):
+        the epilogue accumulates its maxima.
         bias_rows [B, Cout]: replaces the bias by one row per image (the caller has added self.bias into it);
         out_scale: result = (conv + bias + residual) * out_scale -- both folded into the epilogue (split families only)."""
-        amax = None if bounded else ops.unbounded_amax()
-        if amax is not None and in_amax is not None:
-            amax = in_amax                       # an upper bound of max |x| per image the caller already has
+        impl = ops.impl_unbounded()
+        amax = None
+        if not bounded and impl == "hx2":
+            amax = in_amax if in_amax is not None else ops.in_amax_for(x, impl, always=True)
+        produce = feeds_conv and impl == "hx2"
         bias = None if self.bias is None else self.bias.data
         if bias_rows is not None:
             bias = bias_rows
@@ -74,8 +79,9 @@ class Conv(ops.PackedWeightMixin, nn.Module):
         if (ops.impl_unbounded() in ops.SPLIT_IMPLS and self.kernel_size == 3
                 and ops.wino_bx3_pays(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation)):
             return ops.conv2d_wino_bx3(x, self.packed_wino(), bias, residual, dilation=self.dilation, in_amax=amax,
-                                       out_scale=out_scale)
-        return ops.conv2d(x, self.packed(), bias, residual=residual, dilation=self.dilation, in_amax=amax, out_scale=out_scale)
+                                       out_scale=out_scale, want_amax=produce)
+        return ops.conv2d(x, self.packed(), bias, residual=residual, dilation=self.dilation, in_amax=amax, out_scale=out_scale,
+                          want_amax=produce)
 
     def epilogue_folds(self):
         """True when per-image bias rows / out_scale can ride in this convolution's epilogue (split-operand kernels)"""
@@ -83,7 +89,8 @@ class Conv(ops.PackedWeightMixin, nn.Module):
 
     def forward_parts(self, xs, residual=None, out_scale=1.0, in_amax=None):
         """the convolution of torch.cat(xs, dim=1) WITHOUT the concatenation: sum_i conv(xs[i], weight[:, slice_i]), each part
-        taking the previous sum as its residual (the bias rides with the first, out_scale with the last).  1x1 kernels."""
+        taking the previous sum as its residual (the bias rides with the first, out_scale with the last).  1x1 kernels.
+        Every part runs with ITS tensor's maxima (in_amax: one bound for all parts instead)."""
         assert self.kernel_size == 1 and sum(t.shape[1] for t in xs) == self.in_planes
         impl = ops.impl_unbounded()
         acc, c0 = residual, 0
@@ -92,9 +99,11 @@ class Conv(ops.PackedWeightMixin, nn.Module):
             packed = self._cache.get(self.weight, f"direct_{impl}_{c0}_{c1}",
                                      lambda w, a=c0, b=c1: ops.conv_weight(w[:, a:b].contiguous(), impl))
             last = i == len(xs) - 1
+            am = None
+            if impl == "hx2":
+                am = in_amax if in_amax is not None else ops.in_amax_for(t, impl, always=True)
             acc = ops.conv2d(t, packed, self.bias.data if (i == 0 and self.bias is not None) else None, residual=acc,
-                             in_amax=(in_amax if in_amax is not None and ops.unbounded_amax() else ops.unbounded_amax()),
-                             out_scale=out_scale if last else 1.0)
+                             in_amax=am, out_scale=out_scale if last else 1.0)
             c0 = c1
         return acc
 

@@ -58,13 +58,20 @@ class _TembBias:
     never moves: `p.copy_()` -- load_state_dict, an optimiser step -- bumps `p._version` only); a write through `.data` (the
     reference's EMA swap) bumps nothing, so the owning block also clears the cache in its load_state_dict hook and invalidate()"""
 
+    EPOCH = 0                            # bumped by every clear(): part of the model-level bank's tag (models/ncsnpp.py)
+
     def __init__(self):
         self._tag, self._sum = None, None
+        self.preset = None               # this block's rows out of the model's ONE linear launch for all blocks, when it ran
 
     def clear(self):
         self._tag, self._sum = None, None
+        _TembBias.EPOCH += 1
 
     def rows(self, dense, conv, temb, code):
+        if self.preset is not None:      # (single use: set by NCSNpp.forward for this evaluation)
+            rows, self.preset = self.preset, None
+            return rows
         b_d, b_c = dense.bias, conv.bias
         tag = (b_d._version, b_d.data_ptr(), b_c._version, b_c.data_ptr())
         if tag != self._tag:
@@ -187,7 +194,7 @@ class ResnetBlockDDPMpp(_TembBiasOwner, nn.Module):
             x = self.Conv_2(x) if self.conv_shortcut else self.NIN_0(x)
         if fold:                                                   # (x + Conv_1(.)) [/ sqrt 2] in Conv_1's epilogue
             return self.Conv_1(self.GroupNorm_1(h, code), residual=x, bounded=True,
-                               out_scale=INV_SQRT2 if self.skip_rescale else 1.0)
+                               out_scale=INV_SQRT2 if self.skip_rescale else 1.0, feeds_conv=True)
         h = self.Conv_1(self.GroupNorm_1(h, code), bounded=True)
         return _skip(x, h, self.skip_rescale)
 
@@ -217,7 +224,9 @@ class ResnetBlockBigGANpp(_TembBiasOwner, nn.Module):
         parts = None
         # the shortcut Conv_2 convolves the RAW input: its dynamic range comes out of GroupNorm_0's statistics pass (a bound on
         # max |x| also bounds the FIR-resampled x: the taps of every phase are non-negative and sum to one)
-        need_amax = (self.in_ch != self.out_ch or self.up or self.down) and ops.unbounded_amax() is not None
+        # ... unless the input already carries its maxima from the epilogue that produced it (the usual case: a block's output)
+        need_amax = ((self.in_ch != self.out_ch or self.up or self.down) and ops.unbounded_amax() is not None
+                     and (ops.amax_of(x) is None or (x2 is not None and ops.amax_of(x2) is None)))
         amax = None
         if x2 is not None:
             if self.Conv_0.epilogue_folds() and self.Conv_2.kernel_size == 1:
@@ -261,6 +270,7 @@ class ResnetBlockBigGANpp(_TembBiasOwner, nn.Module):
         elif parts is not None:
             x = torch.cat(parts, dim=1)
         if fold:                                                   # (x + Conv_1(h)) [/ sqrt 2] in Conv_1's epilogue
-            return self.Conv_1(h, residual=x, bounded=True, out_scale=INV_SQRT2 if self.skip_rescale else 1.0)
+            return self.Conv_1(h, residual=x, bounded=True, out_scale=INV_SQRT2 if self.skip_rescale else 1.0,
+                               feeds_conv=True)                    # a block's output: shortcuts / skip connections read it raw
         h = self.Conv_1(h, bounded=True)
         return _skip(x, h, self.skip_rescale)

@@ -28,13 +28,34 @@ def _fir(k, scale, device):
     return _KERNEL_CACHE[key]
 
 
+_GAIN_CACHE = {}
+
+
+def _max_phase_gain(k, scale, up):
+    """max over the output phases of sum |tap| of the (separable or 2-D) FIR `k` normalised and scaled as _fir does, after zero
+    insertion by `up`: |resampled x| <= this x max |x|.  1 for every filter the models use ((1,3,3,1), boxes): a bound on the
+    input's maximum then bounds the output's, so the per-image maxima of the f16x2 dynamic range pass through the resampler."""
+    key = (tuple(np.asarray(k, dtype=np.float32).ravel().tolist()), float(scale), int(up))
+    if key not in _GAIN_CACHE:
+        kk = np.abs(_setup_kernel(k) * scale)
+        _GAIN_CACHE[key] = float(max(kk[i::up, j::up].sum() for i in range(up) for j in range(up)))
+    return _GAIN_CACHE[key]
+
+
+def _carry(x, y, gain):
+    if gain <= 1.0 + 1e-6:
+        ops.carry_amax(x, y)
+    return y
+
+
 def upsample_2d(x, k=None, factor=2, gain=1):
     """zero-insert by `factor` and low-pass with `k` (normalised, times gain * factor^2)"""
     assert isinstance(factor, int) and factor >= 1
     k = [1] * factor if k is None else k
     fir = _fir(k, gain * (factor ** 2), x.device)
     p = fir.shape[0] - factor
-    return upfirdn2d(x, fir, up=factor, pad=((p + 1) // 2 + factor - 1, p // 2))
+    y = upfirdn2d(x, fir, up=factor, pad=((p + 1) // 2 + factor - 1, p // 2))
+    return _carry(x, y, _max_phase_gain(k, gain * (factor ** 2), factor))
 
 
 def downsample_2d(x, k=None, factor=2, gain=1):
@@ -43,7 +64,8 @@ def downsample_2d(x, k=None, factor=2, gain=1):
     k = [1] * factor if k is None else k
     fir = _fir(k, gain, x.device)
     p = fir.shape[0] - factor
-    return upfirdn2d(x, fir, down=factor, pad=((p + 1) // 2, p // 2))
+    y = upfirdn2d(x, fir, down=factor, pad=((p + 1) // 2, p // 2))
+    return _carry(x, y, _max_phase_gain(k, gain, 1))
 
 
 def naive_upsample_2d(x, factor=2):
@@ -73,9 +95,10 @@ def conv_downsample_2d(x, w, k=None, factor=2, gain=1, packed=None, bias=None):
     k = [1] * factor if k is None else k
     fir = _fir(k, gain, x.device)
     p = (fir.shape[0] - factor) + (convW - 1)
-    x = upfirdn2d(x, fir, pad=((p + 1) // 2, p // 2))
-    return ops.conv2d_stride2_valid(x, ops.conv_weight(w, ops.impl_unbounded()) if packed is None else packed, bias, convW,
-                                    in_amax=ops.unbounded_amax())
+    xf = _carry(x, upfirdn2d(x, fir, pad=((p + 1) // 2, p // 2)), _max_phase_gain(k, gain, 1))
+    impl = ops.impl_unbounded()
+    return ops.conv2d_stride2_valid(xf, ops.conv_weight(w, impl) if packed is None else packed, bias, convW,
+                                    in_amax=ops.in_amax_for(xf, impl, always=True))
 
 
 class Conv2d(ops.PackedWeightMixin, nn.Module):
@@ -102,4 +125,4 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
         if self.down:                   # the bias rides in the convolution epilogue (= x + bias.reshape(1, -1, 1, 1) afterwards)
             return conv_downsample_2d(x, self.weight, k=self.resample_kernel, packed=packed,
                                       bias=self.bias.data if self.use_bias else None)
-        return ops.conv2d(x, packed, self.bias.data if self.use_bias else None, in_amax=ops.unbounded_amax())
+        return ops.conv2d(x, packed, self.bias.data if self.use_bias else None, in_amax=ops.in_amax_for(x, impl, always=True))

@@ -450,9 +450,10 @@ HX2_DYNAMIC = os.environ.get("IPDM_HX2_DYNAMIC", "1") != "0"
 AMAX_MEASURED = 0                               # fallback absmax passes since import (diagnostics / tests)
 
 
-def dynamic_range():
-    """True when convolutions should produce and consume per-image maxima (the f16x2 family with the dynamic range on)"""
-    return HX2_DYNAMIC and CONV_IMPL == "hx2"
+def dynamic_range(impl=None):
+    """True when convolutions should produce and consume per-image maxima (the f16x2 family with the dynamic range on);
+    impl: the kernel family in use where it is not CONV_IMPL (the score_sde networks: impl_unbounded())"""
+    return HX2_DYNAMIC and (CONV_IMPL if impl is None else impl) == "hx2"
 
 
 AMAX_WAYS, AMAX_SLOT = 8, 128                    # include/ipdm.h "maxima vectors": [B][AMAX_SLOT] floats, 8 ways per image, 16 floats apart
@@ -531,17 +532,22 @@ def carry_amax(src, dst):
     return tag_amax(dst, amax_of(src))
 
 
-def in_amax_for(x):
-    """the `in_amax` argument for a convolution reading x: None (static contract / other kernel families), the attached maxima,
-    or True = measure here (one pass, counted)"""
-    if not dynamic_range() or os.environ.get("IPDM_AMAX_CONSUME", "1") == "0":
+def in_amax_for(x, impl=None, always=False):
+    """the `in_amax` argument for a convolution reading x: None (static contract / other kernel families), the maxima attached to
+    x, or -- where nothing is attached -- a MEASUREMENT (ipdm_absmax_f32: one pass, counted in AMAX_MEASURED), which is then
+    attached to x so that its other consumers find it.  always: dynamic whenever the family is f16x2 (the score_sde networks,
+    whose raw streams overflow the static contract: HX2_DYNAMIC does not apply to them)"""
+    fam = CONV_IMPL if impl is None else impl
+    if fam != "hx2" or not (always or HX2_DYNAMIC) or os.environ.get("IPDM_AMAX_CONSUME", "1") == "0":
         return None
     am = amax_of(x)
     if am is not None:
         return am
     global AMAX_MEASURED
     AMAX_MEASURED += 1
-    return True
+    am = absmax_per_image(x)
+    tag_amax(x, am)
+    return am
 
 
 # ---- score-network glue -----------------------------------------------------------------------
@@ -1077,16 +1083,16 @@ def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=
     image into fp16's range, or the per-image maxima themselves"""
     x = _gpu(x, torch.float32, "x")
     bias_per_image = bias is not None and bias.dim() == 2
-    if bias_per_image and tuple(bias.shape) != (x.shape[0], wq.Cout):
-        raise ValueError(f"conv_bx3: per-image bias {tuple(bias.shape)} != {(x.shape[0], wq.Cout)}")
+    if bias_per_image and (tuple(bias.shape) != (x.shape[0], wq.Cout) or bias.stride(1) != 1):
+        raise ValueError(f"conv_bx3: per-image bias {tuple(bias.shape)} != {(x.shape[0], wq.Cout)} (rows may be strided, not columns)")
     want_act = act_out != ACT_NONE
     want_amax = bool(want_amax) and x.shape[0] <= 65535 and os.environ.get("IPDM_AMAX_PRODUCE", "1") != "0"
     slot_o = amax_slot(x.shape[0], x.device) if want_amax and raw else None
     slot_a = amax_slot(x.shape[0], x.device) if want_amax and want_act else None
     if res_second and (residual is None or not want_act or not raw):
         raise ValueError("conv_bx3: res_second needs a residual and both outputs (act_out, e.g. ACT_COPY; raw=True)")
-    ext = _conv_ext(wq.fmt, in_amax, x, coef is not None or act != ACT_NONE, bias_per_image, out_scale, wq.Cout, slot_o, slot_a,
-                    res_second)
+    ext = _conv_ext(wq.fmt, in_amax, x, coef is not None or act != ACT_NONE, bias_per_image, out_scale,
+                    bias.stride(0) if bias_per_image else 0, slot_o, slot_a, res_second)
     if wq.Cin != x.shape[1]:
         raise ValueError(f"conv_bx3: weight Cin {wq.Cin} != input Cin {x.shape[1]}")
     vol = x.dim() == 5
@@ -1171,15 +1177,16 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
     if U.fmt == "hx2" and in_amax is not None:
         amax_t = absmax_per_image(x) if in_amax is True else in_amax
     bias_per_image = bias is not None and bias.dim() == 2
-    if bias_per_image and tuple(bias.shape) != (B, U.Cout):
-        raise ValueError(f"conv2d_wino_bx3: per-image bias {tuple(bias.shape)} != {(B, U.Cout)}")
+    if bias_per_image and (tuple(bias.shape) != (B, U.Cout) or bias.stride(1) != 1):
+        raise ValueError(f"conv2d_wino_bx3: per-image bias {tuple(bias.shape)} != {(B, U.Cout)} (rows may be strided, not columns)")
 
     want_amax = bool(want_amax) and B <= 65535 and os.environ.get("IPDM_AMAX_PRODUCE", "1") != "0"
     slot_o = amax_slot(B, x.device) if want_amax and raw else None
     slot_a = amax_slot(B, x.device) if want_amax and act_out != ACT_NONE else None
 
     def ext_of(b0, b1):
-        return _conv_ext(U.fmt, None if amax_t is None else amax_t[b0:b1], x[b0:b1], False, bias_per_image, out_scale, U.Cout,
+        return _conv_ext(U.fmt, None if amax_t is None else amax_t[b0:b1], x[b0:b1], False, bias_per_image, out_scale,
+                         bias.stride(0) if bias_per_image else 0,
                          None if slot_o is None else slot_o[b0:b1], None if slot_a is None else slot_a[b0:b1], res_second)
 
     def bias_of(b0, b1):

@@ -170,7 +170,7 @@ def test_philox_noise_source_and_registry():
 
 
 @pytest.mark.parametrize("B,C,G,H,W", [(2, 128, 32, 256, 256), (3, 64, 16, 64, 64), (2, 12, 3, 16, 16),
-                                      (2, 8, 4, 9, 7), (1, 32, 8, 96, 40)])
+                                      (2, 8, 4, 9, 7), (1, 32, 8, 96, 40), (2, 64, 16, 128, 128)])
 def test_groupnorm_swish_vs_torch(B, C, G, H, W):
     """GroupNorm(eps 1e-6) + swish through groupnorm_coef / affine_act vs torch's float64 group_norm: the
     register-resident single-read kernels (planes up to 256x256, 256- and 1024-thread forms) and the generic two-sweep
