@@ -131,15 +131,30 @@ def get_timestep_embedding(timesteps, embedding_dim, max_positions=10000):
 
 
 class NIN(nn.Module):
-    """network-in-network = 1x1 convolution with the weight stored (in_dim, num_units): exactly the packed
-    [1][Cin][Cout] layout of the MFMA convolution, so no repacking is needed"""
+    """network-in-network = 1x1 convolution with the weight stored (in_dim, num_units): exactly the packed [1][Cin][Cout] layout
+    of the fp32-MFMA convolution (no repacking there); the split-operand families pack W^T once per parameter version"""
 
     def __init__(self, in_dim, num_units, init_scale=0.1):
         super().__init__()
         self.W = nn.Parameter(default_init(scale=init_scale)((in_dim, num_units)), requires_grad=True)
         self.b = nn.Parameter(torch.zeros(num_units), requires_grad=True)
+        self._cache = ops.PackedWeightCache()
 
-    def forward(self, x, residual=None):
+    def invalidate(self):
+        self._cache.clear()
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._cache.clear()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def forward(self, x, residual=None, bounded=False):
+        """bounded: x is a GroupNorm output (no activation: |x| <= |gamma| sqrt(group size) + |beta|)"""
+        impl = ops.impl_unbounded()
+        if impl in ops.SPLIT_IMPLS and self.W.shape[0] % 16 == 0 and self.W.shape[1] % 32 == 0:
+            packed = self._cache.get(self.W, "nin_" + impl,
+                                     lambda w: ops.conv_weight(w.t().reshape(w.shape[1], w.shape[0], 1, 1).contiguous(), impl))
+            am = None if bounded or impl != "hx2" else ops.in_amax_for(x, impl, always=True)
+            return ops.conv2d(x, packed, self.b.data, residual=residual, in_amax=am)
         return ops.conv2d(x, self.W.data.view(1, self.W.shape[0], self.W.shape[1]), self.b.data, residual=residual)
 
 

@@ -105,7 +105,7 @@ class AttnBlockpp(nn.Module):
     def forward(self, x):
         C = x.shape[1]
         h = self.GroupNorm_0(x)
-        q, k, v = self.NIN_0(h), self.NIN_1(h), self.NIN_2(h)
+        q, k, v = self.NIN_0(h, bounded=True), self.NIN_1(h, bounded=True), self.NIN_2(h, bounded=True)
         h = ops.attention(q, k, v, int(C) ** (-0.5))
         if not self.skip_rescale:
             return self.NIN_3(h, residual=x)
