@@ -29,7 +29,12 @@ namespace ipdm_conv {
 
 constexpr int BX3_KG = 8;       // K chunks (of 16 input channels) per accumulation group of the 16-pixel configurations
 
-template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS, bool HX = false>
+// ZT (3-D convolutions on small planes): depth slices per workgroup.  A workgroup's weight traffic is K x CO_T x 4 bytes whatever
+// its pixel tile, so the kernel's L2 draw per output is inversely proportional to the pixels a workgroup owns; on 8 x 12 / 8 x 24
+// slices one 128-pixel tile per workgroup asked an XCD's L2 for ~42 B/clk/CU of fragments (it delivers 27-30).  ZT = 2: the
+// workgroup computes the SAME pixel tile of two consecutive depth slices -- every weight fragment feeds twice the MFMAs, the three
+// depth taps of the pair read four input slices instead of six.
+template <int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS, bool HX = false, int ZT = 1>
 struct BxCfg {
   static constexpr int NPC = HX ? 2 : 3;                     // operand pieces (conv_kernel.h: f16x2 / three-way bf16)
   static constexpr int TAPS = KS * KS;
@@ -42,15 +47,19 @@ struct BxCfg {
   // PW == 16: a 32-lane half reads two image rows; a pitch of 0 (mod 16) pixels keeps their 16-byte pieces on
   // disjoint banks for ds_read_b128's lane groups
   static constexpr int PITCH = PW == 32 ? PWP : (PWP + 15) / 16 * 16;
-  static constexpr int PLANE = PHP * PITCH;                  // 16-byte units
+  static constexpr int PLANE_S = PHP * PITCH;                // 16-byte units of one slice's patch
+  static constexpr int PLANE = ZT * PLANE_S;                 // ... of the workgroup's slices, one behind the other
   static constexpr int STAGE = 2 * NPC * PLANE;              // [piece][h 2][PLANE]
-  static constexpr int ITEMS = (2 * PHP * PWP + 255) / 256;  // (pixel, 8-channel group) items per thread
+  static constexpr int ITEMS = (2 * ZT * PHP * PWP + 255) / 256;  // (slice, pixel, 8-channel group) items per thread
+  static constexpr int NPT_T = NPT * ZT;                     // pixel tiles per wave over all slices
   static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE * 16;
 };
 
-template <bool HX, int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS, bool FAST>
+template <bool HX, int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS, bool FAST, int ZT = 1>
 __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
-  using C = BxCfg<NCT, NPT, WCO, WPX, PW, DMAX, KS, HX>;
+  using C = BxCfg<NCT, NPT, WCO, WPX, PW, DMAX, KS, HX, ZT>;
+  constexpr int NPT_T = C::NPT_T;
+  static_assert(ZT == 1 || (ZT == 2 && KS == 3), "two depth slices per workgroup: 3-D 3x3x3 layers");
   constexpr int NPC = C::NPC, FRAG = 64 * NPC;               // FRAG: 16-byte units per (tap, chunk, channel tile)
   static_assert(WCO * WPX == 4, "four waves per workgroup");
   extern __shared__ __align__(16) uint4 lds4[];
@@ -71,7 +80,8 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
   t /= a.tiles_x;
   const int ty = t % a.tiles_y;
   const int bz = t / a.tiles_y;
-  const int b = bz / a.D, z = bz - b * a.D;
+  const int zg = (a.D + ZT - 1) / ZT;            // depth groups per volume
+  const int b = bz / zg, z = (bz - b * zg) * ZT; // first depth slice of this workgroup
   const int y0 = ty * C::PH, x0 = tx * PW;
   const int d = KS == 3 ? (DMAX == 1 ? 1 : a.dil) : 0;
 
@@ -86,8 +96,8 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
   const int n_ct = (a.Cout + 31) / 32;
   // depth taps whose input slice exists (3-D only): a contiguous range around the centre tap
   int kz_lo = 0, n_kz = 1;
-  if (a.kd == 3) {
-    const bool lo = z - a.dil >= 0, hi = z + a.dil < a.D;
+  if (a.kd == 3) {                               // (ZT slices: a tap is walked when ANY slice has its input; the others stage zeros)
+    const bool lo = z + ZT - 1 - a.dil >= 0, hi = z + a.dil < a.D;
     kz_lo = lo ? 0 : 1;
     n_kz = 1 + (lo ? 1 : 0) + (hi ? 1 : 0);
   }
@@ -104,30 +114,34 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
   }
 
   // ---- B operand read offsets (16-byte units inside a stage) ----
-  int b_base[NPT];
+  int b_base[NPT_T];
 #pragma unroll
-  for (int n = 0; n < NPT; ++n) {
-    const int tile = wpx * NPT + n;
+  for (int n = 0; n < NPT_T; ++n) {
+    const int tile = wpx * NPT + n % NPT;
     const int prow = PW == 32 ? tile : tile * 2 + (j >> 4);
     const int pcol = PW == 32 ? j : (j & 15);
-    b_base[n] = h * C::PLANE + (prow + d) * C::PITCH + pcol + d;
+    b_base[n] = h * C::PLANE + (n / NPT) * C::PLANE_S + (prow + d) * C::PITCH + pcol + d;
   }
 
   // ---- staging geometry: item i = (patch pixel p, channel group g) ----
   const int pwv = PW + 2 * d, phv = C::PH + 2 * d;
   const int npos = phv * pwv;
   int it_lds[C::ITEMS], it_gofs[C::ITEMS], it_g[C::ITEMS];
+  [[maybe_unused]] int it_s[C::ITEMS];           // ZT > 1: which of the workgroup's slices
   bool it_valid[C::ITEMS];
 #pragma unroll
   for (int i = 0; i < C::ITEMS; ++i) {
     int idx = tid + i * 256;
-    idx = idx < 2 * npos ? idx : 2 * npos - 1;
+    idx = idx < 2 * ZT * npos ? idx : 2 * ZT * npos - 1;
+    const int sl = idx / (2 * npos);
+    idx -= sl * 2 * npos;
     const int g = idx >= npos ? 1 : 0;
     const int p = idx - g * npos;
     const int r = p / pwv, c = p - r * pwv;
     const int gy = y0 - d + r, gx = x0 - d + c;
     it_g[i] = g;
-    it_lds[i] = g * C::PLANE + r * C::PITCH + c;
+    it_s[i] = sl;
+    it_lds[i] = g * C::PLANE + sl * C::PLANE_S + r * C::PITCH + c;
     it_valid[i] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     it_gofs[i] = it_valid[i] ? gy * a.W + gx : 0;
   }
@@ -144,21 +158,31 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
     c0 = (ch - kzi * n_cc) * 16;
     kz = kz_lo + kzi;
   };
+  // input slice of the workgroup's slice `sl` for depth tap kz, and whether it exists (clamped address when it does not)
+  auto slice_in = [&](int kz, int sl, bool& ok) {
+    const int zi = z + sl + (kz - a.kd / 2) * a.dil;
+    ok = zi >= 0 && zi < a.D && z + sl < a.D;
+    return ok ? zi : (z < a.D ? z : 0);
+  };
   auto load_chunk = [&](int ch) {
     int kz, c0;
     chunk_kz_c0(ch, kz, c0);
-    const int zi = z + (kz - a.kd / 2) * a.dil;
-    const float* xb = a.x + (((size_t)b * a.Cin + c0) * a.D + zi) * HW;
+    bool ok0, ok1 = false;
+    const int zi0 = slice_in(kz, 0, ok0);
+    const float* xb = a.x + (((size_t)b * a.Cin + c0) * a.D + zi0) * HW;
+    [[maybe_unused]] const float* xb1 = xb;
+    if constexpr (ZT > 1) xb1 = a.x + (((size_t)b * a.Cin + c0) * a.D + slice_in(kz, 1, ok1)) * HW;
 #pragma unroll
     for (int i = 0; i < C::ITEMS; ++i) {
+      const float* src = (ZT > 1 && it_s[i]) ? xb1 : xb;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int cl = it_g[i] * 8 + q;
         if constexpr (FAST) {
-          preg[i][q] = xb[(size_t)cl * cs + it_gofs[i]];
+          preg[i][q] = src[(size_t)cl * cs + it_gofs[i]];
         } else {
           float v = 0.f;
-          if (it_valid[i] && c0 + cl < a.Cin) v = xb[(size_t)cl * cs + it_gofs[i]];
+          if (it_valid[i] && c0 + cl < a.Cin) v = src[(size_t)cl * cs + it_gofs[i]];
           preg[i][q] = v;
         }
       }
@@ -167,17 +191,23 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
   auto store_chunk = [&](uint4* st, int ch) {
     int kz, c0;
     chunk_kz_c0(ch, kz, c0);
+    bool zok0 = true, zok1 = true;                 // the slice's input for this depth tap exists (else: zeros)
+    if constexpr (ZT > 1) {
+      (void)slice_in(kz, 0, zok0);
+      (void)slice_in(kz, 1, zok1);
+    }
 #pragma unroll
     for (int i = 0; i < C::ITEMS; ++i) {
       float v[8];
+      const bool item_ok = it_valid[i] && (ZT == 1 || (it_s[i] ? zok1 : zok0));
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         float val = preg[i][q];
         if constexpr (FAST) {
-          val = it_valid[i] ? val : 0.f;
+          val = item_ok ? val : 0.f;
         } else {
           const int ci = c0 + it_g[i] * 8 + q;
-          if (it_valid[i] && ci < a.Cin) {
+          if (item_ok && ci < a.Cin) {
             if (a.coef) {
               const float* cf = a.coef + ((size_t)b * a.Cin + ci) * 3;
               val = (val - cf[0]) * cf[1] + cf[2];
@@ -225,16 +255,19 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
       for (int s = 0; s < NPC; ++s) fr[m][s] = p[ct_ofs[m] + s * 64];
   };
 
-  f32x16 acc[NCT][NPT];
+  f32x16 acc[NCT][NPT_T];
 #pragma unroll
   for (int m = 0; m < NCT; ++m)
 #pragma unroll
-    for (int n = 0; n < NPT; ++n)
+    for (int n = 0; n < NPT_T; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  f32x16 tot[PW == 16 ? NCT : 1][PW == 16 ? NPT : 1];       // group sums added in order (16-pixel configurations)
-  if constexpr (PW == 16) {
+  // group sums added in order (16-pixel configurations, so that the split-K form gives the same bits; the two-slice form is
+  // never split -- a rule of the layer shape, bx3_choose_ksplit -- and accumulates straight through)
+  constexpr bool GROUPED = PW == 16 && ZT == 1;
+  f32x16 tot[GROUPED ? NCT : 1][GROUPED ? NPT : 1];
+  if constexpr (GROUPED) {
 #pragma unroll
     for (int m = 0; m < NCT; ++m)
 #pragma unroll
@@ -251,11 +284,11 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
   __syncthreads();
 
   if (a.dbg) t1 = __builtin_amdgcn_s_memtime();
-  constexpr int STEPS = C::TAPS * NPT;
+  constexpr int STEPS = C::TAPS * NPT_T;
   // operand reads of step s = (tap, pixel tile n): one ds_read_b128 per piece at the tap-shifted pixel
   auto load_B = [&](uint4 (&fr)[NPC], const uint4* cur, auto sc) {
     constexpr int st = decltype(sc)::value;
-    constexpr int tap = st / NPT, n = st % NPT;
+    constexpr int tap = st / NPT_T, n = st % NPT_T;
     constexpr int dy = KS == 3 ? tap / 3 - 1 : 0, dx = KS == 3 ? tap % 3 - 1 : 0;
     const uint4* bp = cur + b_base[n] + (dy * C::PITCH + dx) * d;
 #pragma unroll
@@ -275,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
     // tap, the global loads of the NEXT tap's A fragments) are issued before the six MFMAs of step s.
     static_for<STEPS>([&](auto sc) {
       constexpr int st = decltype(sc)::value;
-      constexpr int tap = st / NPT, n = st % NPT;
+      constexpr int tap = st / NPT_T, n = st % NPT_T;
       if constexpr (st + 1 < STEPS) load_B(bfr[(st + 1) & 1], cur, std::integral_constant<int, st + 1>{});
       if constexpr (n == 0) {
         if constexpr (tap + 1 < C::TAPS) load_A(afr[(tap + 1) & 1], a_cur, tap + 1);
@@ -320,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
 #pragma unroll
         for (int s = 0; s < NPC; ++s) afr[0][m][s] = afr[1][m][s];
     }
-    if constexpr (PW == 16) {
+    if constexpr (GROUPED) {
       if (((ch + 1) % BX3_KG) == 0 || !more) {     // end of an accumulation group (uniform)
 #pragma unroll
         for (int m = 0; m < NCT; ++m)
@@ -363,13 +396,14 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
       bv[m][r] = bias_p[has_bias ? b * a.bias_bstride + (co < a.Cout ? co : a.Cout - 1) : 0];
       if constexpr (HX) sv[m][r] = scale_p[co < n_ct * 32 ? co : 0] * hx_out;
     }
-  constexpr int NBATCH = NPT * NCT;
+  constexpr int NBATCH = NPT_T * NCT;
   float rv[2][16];
-  auto pixel_of = [&](int n, int& gy, int& gx) {
-    const int tile = wpx * NPT + n;
+  auto pixel_of = [&](int n, int& gy, int& gx) {   // n over the pixel tiles of all slices: slice n / NPT
+    const int tile = wpx * NPT + n % NPT;
     gy = y0 + (PW == 32 ? tile : tile * 2 + (j >> 4));
     gx = x0 + (PW == 32 ? j : (j & 15));
   };
+  auto zout_of = [&](int n) { return z + n / NPT; };
   auto load_res = [&](auto qc) {
     constexpr int q = decltype(qc)::value;
     constexpr int n = q / NCT, m = q % NCT;
@@ -383,7 +417,8 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
     // multiplies per residual value)
     const int cs32 = has_res ? (int)co_stride : 0;              // D * H * W < 2^26 (launcher)
     const int lim = a.Cout - 1 - cob, limoff = lim * cs32;
-    const float* const rp = res_p + (has_res ? (((size_t)b * a.Cout + cob) * a.D + z) * HW + (size_t)gy * a.W + gx : 0);
+    const int zr = zout_of(n) < a.D ? zout_of(n) : a.D - 1;
+    const float* const rp = res_p + (has_res ? (((size_t)b * a.Cout + cob) * a.D + zr) * HW + (size_t)gy * a.W + gx : 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int dco = (r & 3) + 8 * (r >> 2);
@@ -407,9 +442,9 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
     for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(rv[q & 1][r]));
     int gy, gx;
     pixel_of(n, gy, gx);
-    if (gy < a.H && gx < a.W) {
+    if (gy < a.H && gx < a.W && zout_of(n) < a.D) {
       const int cob = co0 + (wco * NCT + m) * 32 + 4 * h;      // channel of r = 0; r adds (r & 3) + 8 * (r >> 2)
-      size_t ob = (((size_t)b * a.Cout + cob) * a.D + z) * HW + (size_t)gy * a.W + gx;
+      size_t ob = (((size_t)b * a.Cout + cob) * a.D + zout_of(n)) * HW + (size_t)gy * a.W + gx;
       // (opaque: hipcc otherwise folds the channel step back into the product chain and recomputes the whole 64-bit index --
       //  six quarter-rate multiplies -- for every one of the 16 values; the step itself is a scalar, D * H * W < 2^26: launcher)
       asm volatile("" : "+v"(ob));
@@ -420,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
         if (cob + dco < a.Cout) {
           const size_t o = ob + (size_t)((unsigned)dco * os32);
           float v;
-          if constexpr (PW == 16) v = tot[m][n][r];
+          if constexpr (GROUPED) v = tot[m][n][r];
           else v = acc[m][n][r];
           if constexpr (HX) v *= sv[m][r];
           if (!finish) {
@@ -459,15 +494,16 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
   }
 }
 
-template <bool HX, int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS, bool FAST>
+template <bool HX, int NCT, int NPT, int WCO, int WPX, int PW, int DMAX, int KS, bool FAST, int ZT = 1>
 int launch_bx3(ConvArgs a, hipStream_t s) {
-  using C = BxCfg<NCT, NPT, WCO, WPX, PW, DMAX, KS, HX>;
+  using C = BxCfg<NCT, NPT, WCO, WPX, PW, DMAX, KS, HX, ZT>;
   a.tiles_x = (a.W + PW - 1) / PW;
   a.tiles_y = (a.H + C::PH - 1) / C::PH;
   a.co_tiles = (a.Cout + C::CO_T - 1) / C::CO_T;
-  const int64_t nblk = (int64_t)a.B * a.D * a.tiles_x * a.tiles_y * a.co_tiles * a.ksplit;
+  if (ZT > 1 && a.ksplit > 1) return IPDM_EUNSUPPORTED;
+  const int64_t nblk = (int64_t)a.B * ((a.D + ZT - 1) / ZT) * a.tiles_x * a.tiles_y * a.co_tiles * a.ksplit;
   if (nblk > 0x7fffffff || (int64_t)a.D * a.H * a.W >= (1 << 26)) return IPDM_EUNSUPPORTED;   // (32-bit plane offsets in the epilogue)
-  auto kern = conv_bx3_kernel<HX, NCT, NPT, WCO, WPX, PW, DMAX, KS, FAST>;
+  auto kern = conv_bx3_kernel<HX, NCT, NPT, WCO, WPX, PW, DMAX, KS, FAST, ZT>;
   static bool attr_set = false;
   if (!attr_set) {
     if (C::LDS_BYTES > 64 * 1024) {
@@ -505,8 +541,29 @@ static int bx3_forced_cfg() {
   return v;
 }
 
+// two depth slices per workgroup (BxCfg): undilated 3x3x3 layers on slices at most 16 pixels wide with >= 128 output channels --
+// a rule of the LAYER SHAPE only (the form accumulates straight through, so it must never alternate with the grouped one)
+bool bx3_two_slices(int D, int Cin, int Cout, int W, int k, int dil, int kd) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("IPDM_BX3_ZT2");
+    on = e ? atoi(e) : 1;
+  }
+  return on && kd == 3 && k == 3 && dil == 1 && D >= 2 && W <= 16 && Cout >= 128 && Cin % 16 == 0;
+}
+
+template <bool HX>
+static int launch_bx3_zt2(const ConvArgs& a, hipStream_t s) {
+  const bool fast = a.Cin % 16 == 0 && a.act == IPDM_ACT_NONE && !a.coef;
+  // (two channel tiles x two pixel tiles per wave and slice -- half the LDS operand reads per MFMA -- was measured too: 80 spilled
+  //  registers, 4.64 ms against 3.90 per 256 -> 256 launch of config 4; one channel tile per wave it is)
+  return fast ? launch_bx3<HX, 1, 4, 4, 1, 16, 1, 3, true, 2>(a, s) : launch_bx3<HX, 1, 4, 4, 1, 16, 1, 3, false, 2>(a, s);
+}
+
 int conv_bx3_dispatch(const ConvArgs& a, int ks, hipStream_t s) {
   const int f = bx3_forced_cfg();
+  if (ks == 3 && a.ksplit <= 1 && f < 0 && bx3_two_slices(a.D, a.Cin, a.Cout, a.W, ks, a.dil, a.kd))
+    return a.hx ? launch_bx3_zt2<true>(a, s) : launch_bx3_zt2<false>(a, s);
   if (a.W <= 16) {
     // 128 output channels per workgroup (a wave: 32 channels x all four 32-pixel tiles) where that still leaves two workgroups
     // per CU: a weight fragment then feeds 12 MFMAs instead of 6 -- the 64-channel form draws ~42 B/clk/CU of fragments from L2,
@@ -569,6 +626,7 @@ int bx3_choose_ksplit(int B, int D, int Cin, int Cout, int H, int W, int k, int 
     forced = e ? atoi(e) : -1;
   }
   if (W > 16 || forced == 0) return 1;
+  if (bx3_two_slices(D, Cin, Cout, W, k, dil, D > 1 && k == 3 ? 3 : 1)) return 1;      // (that form is never split)
   const int64_t tiles = (int64_t)B * D * ((H + 7) / 8) * ((Cout + 63) / 64);
   const int n_chunks = ((Cin + 15) / 16) * (D > 1 && k == 3 ? 3 : 1);
   const int n_groups = (n_chunks + BX3_KG - 1) / BX3_KG;

@@ -1316,3 +1316,36 @@ def test_residual_into_the_second_output_only(ops, fmt):
     assert torch.equal(p3, ops.conv3d(x3, wq3)) and torch.equal(s3, ops.conv3d(x3, wq3, residual=r3))
     with pytest.raises(ValueError):
         ops.conv_bx3(x3, wq3, act_out=ops.ACT_COPY, res_second=True)      # no residual
+
+
+@pytest.mark.parametrize("fmt", ["hx2", "bx3"])
+@pytest.mark.parametrize("B,Cin,Cout,D,Hh,Ww", [(2, 128, 128, 8, 8, 12), (1, 64, 128, 5, 8, 12), (1, 128, 256, 3, 6, 16),
+                                                  (1, 256, 256, 2, 8, 12), (2, 32, 128, 7, 11, 9)])
+def test_conv3d_two_slices_per_workgroup(ops, fmt, B, Cin, Cout, D, Hh, Ww):
+    """undilated 3x3x3 layers on slices <= 16 pixels wide with >= 128 output channels run the two-slice form of the direct kernel
+    (conv_bx3.hip, ZT = 2: a workgroup owns the same pixel tile of two consecutive depth slices -- half the weight traffic per
+    output).  Even and odd depths, ragged planes, bias / residual / activated copy / maxima / residual-into-second-output, against
+    a float64 convolution; IPDM_BX3_ZT2=0 (the one-slice form) must agree to rounding."""
+    gen = torch.Generator().manual_seed(20 + D)
+    x = torch.randn(B, Cin, D, Hh, Ww, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (Cin * 27) ** 0.5
+    b = torch.randn(Cout, generator=gen)
+    r = torch.randn(B, Cout, D, Hh, Ww, generator=gen)
+    want = F.conv3d(x.double(), w.double(), b.double(), padding=1) + r.double()
+    wq = ops.conv_bx3_weight(w.cuda(), fmt=fmt)
+    xg, rg = x.cuda(), r.cuda()
+    am = ops.absmax_per_image(xg) if fmt == "hx2" else None
+    out, act = ops.conv3d(xg, wq, b.cuda(), residual=rg, act_out=ops.ACT_ELU, in_amax=am, want_amax=True)
+    tol = 4e-6 * max(1.0, float(want.abs().max()))
+    assert (out.cpu().double() - want).abs().max() < tol
+    assert (act.cpu().double() - F.elu(want)).abs().max() < tol
+    assert torch.equal(ops.amax_value(ops.amax_of(out)), out.abs().amax(dim=(1, 2, 3, 4)))
+    assert torch.equal(ops.amax_value(ops.amax_of(act)), act.abs().amax(dim=(1, 2, 3, 4)))
+    path, summed = ops.conv3d(xg, wq, b.cuda(), residual=rg, act_out=ops.ACT_COPY, in_amax=am, res_second=True)
+    assert torch.equal(summed, out) and (path.cpu().double() - (want - r.double())).abs().max() < tol
+    plain = ops.conv3d(xg, wq, in_amax=am)
+    assert (plain.cpu().double() - F.conv3d(x.double(), w.double(), padding=1)).abs().max() < tol
+    # a sample's bits do not depend on the batch it is computed in (the form is a rule of the layer shape)
+    one = ops.conv3d(xg[:1].contiguous(), wq, b.cuda(), residual=rg[:1].contiguous(),
+                     in_amax=None if am is None else am[:1].contiguous())
+    assert torch.equal(one[0], out[0])
