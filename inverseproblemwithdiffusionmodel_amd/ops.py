@@ -52,6 +52,18 @@ def _inplace_operand(t, dtype, name):
 _STREAM_OF_DEVICE = {}
 
 
+def _written(*tensors):
+    """the kernels write through raw pointers, which torch's version counters never see: every op that stores into an EXISTING
+    tensor reports it here, so that whatever was cached under (version, data_ptr) of that storage -- per-image maxima
+    (`_ipdm_amax`), statistics partials (`_ipdm_partials`) -- goes stale for every alias (views share the counter).  Without this
+    the sampler state, updated in place by the fused Langevin / proximal kernel, kept the maxima measured on its FIRST
+    iteration: the segmentation network's first convolution then overflowed fp16 as the state grew (caught by
+    test_guided_sense_trajectory_vs_oracle).  Host-side bookkeeping only; no launch."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+
+
 def _stream():
     st = torch.cuda.current_stream()
     h = st.cuda_stream
@@ -207,6 +219,7 @@ def sense_l2prox(z_re, z_im, y, sens_f32, mask_u8, coef, out_re=None, out_im=Non
     _check_work(work, B, sens_f32.shape[0], H, W, "sense_l2prox")
     call("ipdm_sense_l2prox_f32", _ptr(z_re), _ptr(z_im), _ptr(y), _ptr(sens_f32), _ptr(mask_u8), mask_u8.shape[0],
          float(coef), _ptr(out_re), _ptr(out_im), _ptr(work), B, sens_f32.shape[0], H, W, _stream())
+    _written(out_re, out_im)
     return out_re, out_im
 
 
@@ -228,6 +241,7 @@ def ald_sense_step(x_re, x_im, g_re, g_im, y, sens_f32, mask_u8, work, step=0.0,
          float(step), float(noise_scale), int(seed), int(sample_offset), int(step_id), _ptr(dev_sched),
          _ptr(y), _ptr(sens_f32), _ptr(mask_u8), mask_u8.shape[0], float(coef), _ptr(work), B, sens_f32.shape[0], H, W,
          _stream())
+    _written(x_re, x_im)
 
 
 SC_L2PENALTY, SC_CLOSED_FORM, SC_PROJECTION = 0, 1, 2
@@ -249,6 +263,7 @@ def singlecoil_prox(z_re, z_im, y, mask_u8, coef, mode, out_re=None, out_im=None
         _check_work(work, B, 1, H, W, "singlecoil_prox")
     call("ipdm_singlecoil_prox_f32", _ptr(z_re), _ptr(z_im), _ptr(y), _ptr(mask_u8), mask_u8.shape[0], float(coef),
          int(mode), _ptr(out_re), _ptr(out_im), _ptr(work), B, H, W, _stream())
+    _written(out_re, out_im)
     return out_re, out_im
 
 
@@ -267,6 +282,7 @@ def ald_singlecoil_step(x_re, x_im, g_re, g_im, y, mask_u8, mode, step=0.0, nois
     call("ipdm_ald_singlecoil_step_f32", _ptr(x_re), _ptr(x_im), _ptr(g_re), _ptr(g_im), _ptr(noise_re), _ptr(noise_im),
          float(step), float(noise_scale), int(seed), int(sample_offset), int(step_id), _ptr(dev_sched), _ptr(y),
          _ptr(mask_u8), mask_u8.shape[0], float(coef), int(mode), _ptr(work), B, H, W, _stream())
+    _written(x_re, x_im)
 
 
 def langevin_step(x, g, step=0.0, noise_scale=0.0, noise=None, seed=0, sample_offset=0, step_id=0, dev_sched=None):
@@ -282,6 +298,7 @@ def langevin_step(x, g, step=0.0, noise_scale=0.0, noise=None, seed=0, sample_of
     n_samples = x.shape[0]
     call("ipdm_langevin_step_f32", _ptr(x), _ptr(g), _ptr(noise), float(step), float(noise_scale), int(seed),
          int(sample_offset), int(step_id), _ptr(dev_sched), n_samples, x.numel() // max(n_samples, 1), _stream())
+    _written(x)
     return x
 
 
@@ -370,6 +387,7 @@ def axpy_sched(y, x, scale=0.0, dev_sched=None, mask=None):
         if y.numel() % period:
             raise ValueError("axpy_sched: mask does not tile y")
     call("ipdm_axpy_sched_f32", _ptr(y), _ptr(x), _ptr(mask), period, _ptr(dev_sched), float(scale), y.numel(), _stream())
+    _written(y)
     return y
 
 
@@ -586,6 +604,7 @@ def affine_act(x, coef, act=ACT_NONE, out=None):
     B, C = x.shape[:2]
     out = torch.empty_like(x) if out is None else out
     call("ipdm_affine_act_f32", _ptr(x), _ptr(coef), _ptr(out), B, C, x.numel() // max(B * C, 1), act, _stream())
+    _written(out)
     return tag_amax(out, getattr(coef, "_ipdm_amax_bound", None))     # (every activation code shrinks |.|)
 
 
@@ -593,13 +612,16 @@ def act(x, code, out=None):
     x = _gpu(x, torch.float32, "x")
     out = torch.empty_like(x) if out is None else out
     call("ipdm_act_f32", _ptr(x), _ptr(out), x.numel(), code, _stream())
-    return carry_amax(x, out)
+    am = amax_of(x)                                 # (every activation code shrinks |.|: the input's bound holds, in place too)
+    _written(out)
+    return tag_amax(out, am)
 
 
 def scale_shift(x, a, b, out=None):
     x = _gpu(x, torch.float32, "x")
     out = torch.empty_like(x) if out is None else out
     call("ipdm_scale_shift_f32", _ptr(x), _ptr(out), x.numel(), float(a), float(b), _stream())
+    _written(out)
     return out
 
 
@@ -609,6 +631,7 @@ def add(x, y, out=None):
         raise ValueError(f"ipdm add: shapes differ {tuple(x.shape)} vs {tuple(y.shape)}")
     out = torch.empty_like(x) if out is None else out
     call("ipdm_add_f32", _ptr(x), _ptr(y), _ptr(out), x.numel(), _stream())
+    _written(out)
     return out
 
 
@@ -620,6 +643,7 @@ def div_sigma(x, sigmas, labels=None, out=None):
     out = torch.empty_like(x) if out is None else out
     B = x.shape[0]
     call("ipdm_div_sigma_f32", _ptr(x), _ptr(sigmas), _ptr(labels), _ptr(out), B, x.numel() // max(B, 1), _stream())
+    _written(out)
     return out
 
 
@@ -649,6 +673,7 @@ def bilinear(x, size, out=None, accumulate=False, act=ACT_NONE, want_amax=False)
         accumulate = False
     slot = amax_slot(B, x.device) if want_amax and B <= 65535 else None
     call("ipdm_bilinear_f32", _ptr(x), _ptr(out), B * C, H, W, oh, ow, int(bool(accumulate)), act, C, _ptr(slot), _stream())
+    _written(out)
     return tag_amax(out, slot)
 
 
@@ -663,6 +688,7 @@ def trilinear(x, size, out=None, accumulate=False, act=ACT_NONE, want_amax=False
     slot = amax_slot(B, x.device) if want_amax and B <= 65535 else None
     call("ipdm_trilinear_f32", _ptr(x), _ptr(out), B * C, D, H, W, od, oh, ow, int(bool(accumulate)), act, C, _ptr(slot),
          _stream())
+    _written(out)
     return tag_amax(out, slot)
 
 
@@ -733,6 +759,7 @@ def axpby(x, y, a, b, out=None):
         raise ValueError(f"ipdm axpby: shapes differ {tuple(x.shape)} vs {tuple(y.shape)}")
     out = torch.empty_like(x) if out is None else out
     call("ipdm_axpby_f32", _ptr(x), _ptr(y), _ptr(out), x.numel(), float(a), float(b), _stream())
+    _written(out)
     return out
 
 
@@ -745,6 +772,7 @@ def sample_axpy2(x, y, a, z=None, c=None, out=None):
     c = None if c is None else _gpu(c.to(torch.float32), torch.float32, "c")
     call("ipdm_sample_axpy2_f32", _ptr(x), _ptr(y), _ptr(z), _ptr(a), _ptr(c), _ptr(out), n,
          x.numel() // max(n, 1), _stream())
+    _written(out)
     return out
 
 
@@ -888,6 +916,7 @@ def conv2d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1,
         e0.record()
     call("ipdm_conv2d_f32", _ptr(x), _ptr(wt), _ptr(bias), _ptr(coef), act, _ptr(residual), _ptr(out), _ptr(out_act),
          act_out, B, Cin, Cout, H, W, k, dilation, int(bool(pool2)), _stream())
+    _written(out)
     if CONV_TRACE is not None:
         e1.record()
         CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, dil=dilation, res=residual is not None,
@@ -1132,6 +1161,7 @@ def conv_bx3(x, wq, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=
         CONV_TRACE.append(dict(B=B * D, Cin=Cin, Cout=wq.Cout, H=H, W=W, k=k, dil=dilation, bx3=True, fmt=wq.fmt, res=residual is not None,
                                n_out=int(raw) + int(want_act),
                                taps3d=wq.kk if vol else None, e0=e0, e1=e1))
+    _written(out)                                   # (a caller's `out=` tensor: whatever was cached on it is stale)
     tag_amax(out, slot_o)
     tag_amax(out_act, slot_a)
     return (out, out_act) if want_act else out
@@ -1286,4 +1316,5 @@ def adam_ascent(x, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8):
             raise ValueError(f"adam_ascent: {n} does not match x")
     call("ipdm_adam_ascent_f32", _ptr(x), _ptr(g), _ptr(m), _ptr(v), x.numel(), float(lr), float(betas[0]), float(betas[1]),
          float(eps), int(step), _stream())
+    _written(x, m, v)
     return x

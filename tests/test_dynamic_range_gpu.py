@@ -271,3 +271,28 @@ def test_temporal_network_never_measures(ops):
     labels = torch.tensor([3, 9])
     for s in (1.0, 1.0e-4, 1.0e5):
         _check_net(ops, net, _rescale_unnormalised_stream(sd, s), x, labels, scorenet3d.ncsn3d_shallow, 1e-4)
+
+
+def test_raw_pointer_writes_invalidate_attached_maxima(ops):
+    """the kernels write through raw pointers, which torch's version counters do not see by themselves: every op that stores
+    into an existing tensor bumps the counter (ops._written), so maxima attached to ANY alias of that storage go stale.  The
+    sampler state is the case that matters: it is updated in place by the fused Langevin / proximal kernels every iteration and
+    read by the segmentation network's first convolution through persistent views."""
+    x = torch.randn(4, 1, 16, 16, device="cuda")
+    lo, hi = x[:2], x[2:]                                          # persistent views, as the samplers keep them
+    am = ops.in_amax_for(lo, "hx2", always=True)                   # measured and attached
+    assert ops.amax_of(lo) is am and torch.equal(ops.amax_value(am), lo.abs().amax(dim=(1, 2, 3)))
+    ops.langevin_step(hi, torch.ones_like(hi), step=100.0)         # writes the OTHER half of the storage: same counter
+    assert ops.amax_of(lo) is None
+    am2 = ops.in_amax_for(lo, "hx2", always=True)
+    assert ops.amax_of(lo) is am2
+    ops.axpy_sched(lo, torch.ones_like(lo), scale=1e3)             # in place on the tagged view itself
+    assert ops.amax_of(lo) is None and float(lo.abs().max()) > 500
+    y = torch.randn(2, 3, 8, 8, device="cuda")
+    ops.tag_amax(y, ops.absmax_per_image(y))
+    ops.add(y, y, out=y)
+    assert ops.amax_of(y) is None
+    z = torch.randn(2, 3, 8, 8, device="cuda")
+    ops.tag_amax(z, ops.absmax_per_image(z))
+    ops.act(z, ops.ACT_ELU, out=z)                                 # an activation in place keeps a valid BOUND
+    assert ops.amax_of(z) is not None and (ops.amax_value(ops.amax_of(z)) >= z.abs().amax(dim=(1, 2, 3))).all()
