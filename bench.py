@@ -283,7 +283,7 @@ def main():
                   "bx3": "f32 (convolutions: exact bf16x3 split on the bf16 MFMA, fp32 accumulate)",
                   "hx2": ("f32 (convolutions: operands as two fp16 pieces = 22 significand bits + 2 signs, three fp16 MFMAs per "
                           "product, fp32 accumulate; every image scaled into fp16's range by an exact power of two from its "
-                          "producer's per-image maxima: any fp32 input, DESIGN.md 4.1e)" if ops.dynamic_range() else
+                          "producer's per-image maxima: any fp32 input, DESIGN.md 4.2)" if ops.dynamic_range() else
                           "f32 (convolutions: two fp16 pieces per operand, three fp16 MFMAs per product, fp32 accumulate; STATIC range "
                           "contract |x| < 65504, fp32-faithful for activations of O(1) and above only: IPDM_HX2_DYNAMIC=0)")}[ops.CONV_IMPL],
         "data": "synthetic",
