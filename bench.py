@@ -311,7 +311,7 @@ def main():
         reps = [engine.conv_census(prob.scorenet, x, labels) for _ in range(3)]
         flops = sum(r["flops"] for r in reps[0])
         # Winograd F(2x2,3x3) launches execute 16 instead of 36 multiply-adds per 2x2 output tile
-        executed = sum(r["flops"] / (2.25 if r.get("wino") else 1.0) for r in reps[0])
+        executed = sum(r["flops"] / (1.5 if r.get("wino1d") else 2.25 if r.get("wino") else 1.0) for r in reps[0])
         n_wino = sum(1 for r in reps[0] if r.get("wino"))
         # algorithmic HBM bytes of a launch: input + (residual) read once, each requested output written once,
         # weights read once
@@ -337,7 +337,7 @@ def main():
         mfma_per_product = 3.0 if ops.CONV_IMPL == "hx2" else 6.0
         # 16-bit MFMA FLOPs actually executed: three (fp16 pair) or six (bf16 triple) per fp32 multiply-add, 2.25x fewer on
         # the Winograd launches
-        flops_bx3 = sum(r["flops"] / (2.25 if r.get("wino") else 1.0) for r in reps[0] if r.get("bx3"))
+        flops_bx3 = sum(r["flops"] / (1.5 if r.get("wino1d") else 2.25 if r.get("wino") else 1.0) for r in reps[0] if r.get("bx3"))
         common = {
             "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": bytes_alg, "launches_per_step": len(reps[0]),

@@ -1,0 +1,537 @@
+// 3x3 convolution as ONE-DIMENSIONAL Winograd F(2,3) along x, direct along y, on f16x2 operands (conv_kernel.h).
+//
+//   Y[y][2 px] = A^T sum_ky [ (G g[ky]) (.) (B^T d[y + ky]) ]        per output row y and pair of pixels, 4-pixel row patch d
+//
+// The three rows of the filter accumulate into the SAME accumulator, so there are 4 positions (x) instead of the 16 of
+// conv_wino_bx3.hip, each a channel contraction with K = 3 Cin.  For the register budget of that kernel (128 accumulator
+// registers per wave, 8 waves) a workgroup therefore holds 128 output channels x 8 rows x 32 pixels -- twice the channels of the
+// 2-D form over the same pixel block -- and draws 12 instead of 2 x 16 weight values per (co, ci) from L2: 96 + 26 KiB per
+// 16-channel chunk against 2 x (64 + 21).  It pays for that with 1.5x the matrix instructions (6 instead of 4 multiply-adds per
+// output, co, ci), which the 2-D kernel has to spare: its chunk loop waits on L2 weight fragments, not on the matrix pipe.
+// The exchange of the epilogue (4 positions) is half the 2-D form's per output, the input transform a quarter.
+//
+// Workgroup = 512 threads; wave w = (xi = w & 3, co half = w >> 2) owns position xi for two 32-channel tiles x four 32-column
+// blocks (rows 2nb, 2nb+1 x 16 pixel pairs): acc[2][4] = 128 registers.
+//   A (U fragments): [pos = ky*4 + xi][ci/16][co/32][piece 2][lane] 16-byte units, global -> VGPR, two slots, requested one
+//        filter row (24 MFMAs) ahead.
+//   B (V = B^T d, rows): raw rows by wave-private 16-byte LDS-DMA exactly as the 2-D kernel's (same 10 x 40 region per
+//        channel), transformed along x, split once into packed fp16 pairs and stored as
+//        Vs[row 12][xi 4][piece 2][q>>1][h][q&1][tile 16] words (channel pair cp = 4h + q); a staged row serves three filter rows.
+// Two 48.75 KiB V stages + 32 KiB raw; the epilogue's exchange buffer M[xi 4][co 64][col 32] overlays the stage last read.
+// Eligible: 3x3, dilation 1, Cin % 32 == 0, Cout % 128 == 0, W % 4 == 0, 16-byte aligned input (launcher).
+#include "conv_kernel.h"
+
+namespace ipdm_conv {
+
+namespace {
+
+constexpr int Y_KC = 16;
+constexpr int Y_CO = 128;
+constexpr int Y_ROWS = 8, Y_TX = 16;                 // output rows / pixel pairs per row of a workgroup's block
+constexpr int Y_VROWS = 12;                          // 10 staged rows + 2 that only the idle lanes of the third item write
+constexpr int Y_RS = 1040;                           // words per staged row: 16 (xi, piece, q>>1) x 64 + 16 (bank offset of a row)
+constexpr int Y_STAGE = Y_VROWS * Y_RS;              // 12480 words
+constexpr int Y_RAW = 8 * 1024;                      // eight wave-private 4 KiB blocks
+constexpr size_t Y_LDS_BYTES = (2 * (size_t)Y_STAGE + Y_RAW) * 4;
+constexpr float HX1_PRESCALE = 0.5f;                 // the 1-D input transform at most doubles a value
+constexpr int Y_QC = 10, Y_RC4 = 40, Y_QN = 100;     // quads / floats per raw row, quads per channel
+static_assert(4 * 64 * 32 <= Y_STAGE, "the exchange buffer fits a V stage");
+
+__device__ __forceinline__ float wino1d_U(const float* g, int p) {       // p = ky*4 + xi
+  const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+  const int ky = p >> 2, xi = p & 3;
+  return G[xi][0] * g[ky * 3 + 0] + G[xi][1] * g[ky * 3 + 1] + G[xi][2] * g[ky * 3 + 2];
+}
+
+// one workgroup per output channel: inv_scale[co] = 2^-k with max |U| * 2^k in [2^13, 2^14), times 1 / HX1_PRESCALE
+__global__ __launch_bounds__(256) void wino1d_scale_kernel(const float* __restrict__ w, float* __restrict__ inv_scale, int Cout,
+                                                           int Cin, int n_co_pad) {
+  __shared__ float red[256];
+  const int co = blockIdx.x;
+  float m = 0.f;
+  if (co < Cout)
+    for (int i = threadIdx.x; i < Cin * 12; i += 256) m = fmaxf(m, fabsf(wino1d_U(w + ((size_t)co * Cin + i / 12) * 9, i % 12)));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && co < n_co_pad) {
+    int e = 0;
+    const float mx = red[0];
+    if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &e);
+    inv_scale[co] = (mx > 0.f && mx < INFINITY ? ldexpf(1.f, e - 14) : 1.f) / HX1_PRESCALE;
+  }
+}
+
+__global__ __launch_bounds__(256) void wino1d_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                            const float* __restrict__ inv_scale, int Cout, int Cin, int n_cc,
+                                                            int n_ct) {
+  const int64_t total = (int64_t)12 * n_cc * n_ct * 512;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int q = (int)(i & 7), r = (int)((i >> 3) & 31), h = (int)((i >> 8) & 1);
+    const int64_t rest = i >> 9;
+    const int ct = (int)(rest % n_ct);
+    const int cc = (int)((rest / n_ct) % n_cc);
+    const int p = (int)(rest / ((int64_t)n_ct * n_cc));
+    const int co = ct * 32 + r, ci = cc * 16 + 8 * h + q;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) v = wino1d_U(w + ((size_t)co * Cin + ci) * 9, p) * (1.f / (inv_scale[co] * HX1_PRESCALE));
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const int64_t base = rest * 2 * 512 + h * 256 + r * 8 + q;
+    out[base] = __builtin_bit_cast(unsigned short, hi);
+    out[base + 512] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_tiles) {
+  extern __shared__ __align__(16) float lds[];
+  unsigned* const ldsw = reinterpret_cast<unsigned*>(lds);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, j = lane & 31;
+  const int xi = wave & 3, chh = wave >> 2;
+  const int HW = a.H * a.W;
+  const int n_cc = a.Cin / Y_KC, n_ct = a.Cout / 32;
+  const int n_chunks = n_cc;                                   // even, >= 2 (launcher)
+  unsigned long long t0 = 0, t1 = 0, t_loop = 0, t_epi = 0, tq = 0;   // tuning stamps (a.dbg)
+  if (a.dbg) t0 = __builtin_amdgcn_s_memtime();
+
+  // ---- this workgroup's tile list (XCD-aware, as conv_wino_bx3_wide_kernel) ----
+  const int S = gridDim.x / 8;
+  const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+  const int q8 = total_tiles / 8, r8 = total_tiles % 8;
+  const int x_start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int t_end = x_start + q8 + (xcd < r8 ? 1 : 0);
+  int tile = x_start + slot;
+  if (tile >= t_end) return;
+
+  struct Geo { int b, y0, x0, cob; };
+  auto geo_of = [&](int L) {
+    Geo g;
+    g.cob = L % a.co_tiles;
+    int t = L / a.co_tiles;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    g.y0 = (t % a.tiles_y) * Y_ROWS;
+    g.x0 = tx * (2 * Y_TX);
+    g.b = t / a.tiles_y;
+    return g;
+  };
+
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((size_t)a.B * a.Cin * HW * 4), 0x00020000);
+  float* const rs = lds + 2 * Y_STAGE;
+
+  // raw stage: wave w fetches channels 2w, 2w+1 of a chunk (2 x 100 quads) into its own block, four 16-byte LDS-DMA instructions
+  int dma_off[4];
+  int dma_b = 0;
+  auto set_dma_geo = [&](const Geo& g) {
+    dma_b = g.b;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = k * 64 + lane;
+      const int cl = e / Y_QN, qq = e - cl * Y_QN;
+      const int cin = 2 * wave + cl;
+      const int rr = qq / Y_QC, qc = qq - rr * Y_QC;
+      const int gy = g.y0 - 1 + rr, gx0 = g.x0 - 4 + 4 * qc;
+      const bool ok = e < 2 * Y_QN && gy >= 0 && gy < a.H && gx0 >= 0 && gx0 < a.W;
+      dma_off[k] = ok ? (cin * HW + gy * a.W + gx0) * 4 : 0x40000000;
+    }
+  };
+  auto issue_dma = [&](int chunk) {
+    [[maybe_unused]] const int soff = (int)(((size_t)dma_b * a.Cin + chunk * Y_KC) * HW * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(rs + (wave * 4 + k) * 256), 16,
+                                               dma_off[k], soff, 0, 0);
+#endif
+    }
+  };
+
+  // ---- producer: this thread's three (row, pixel pair) items of the wave's channel pair ----
+  const int pt = lane & 15, rsub = lane >> 4;
+  const bool pfirst = pt == 0, plast = pt == Y_TX - 1;
+  struct Raw { float2 qa, qb; float ea, eb; };
+  Raw raw[3];
+  auto read_items = [&]() {
+    const float* rp = rs + wave * 1024 + rsub * Y_RC4 + 2 * pt + 2;       // -> column 2pt+2 of row rsub, first channel
+    const int edge = pfirst ? 1 : 4;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      raw[it].qa = *reinterpret_cast<const float2*>(rp + it * 4 * Y_RC4 + 2);
+      raw[it].ea = rp[it * 4 * Y_RC4 + edge];
+      raw[it].qb = *reinterpret_cast<const float2*>(rp + Y_QN * 4 + it * 4 * Y_RC4 + 2);
+      raw[it].eb = rp[Y_QN * 4 + it * 4 * Y_RC4 + edge];
+    }
+  };
+  [[maybe_unused]] float hx_in = HX1_PRESCALE, hx_out = 1.f;
+  auto hx_scales_of = [&](int b, float& s_in, float& s_out) {
+    s_in = HX1_PRESCALE;
+    s_out = 1.f;
+    if (a.in_amax) {
+      float sd, si;
+      hx_dynamic_scale(ipdm_amax_read(a.in_amax + (size_t)b * IPDM_AMAX_SLOT), sd, si);
+      s_in = HX1_PRESCALE * sd;
+      s_out = si;
+    }
+  };
+  // word offset of this thread's stores inside a staged row: channel pair cp = wave -> k half cp >> 2, q = cp & 3
+  const int v_st = ((wave & 3) >> 1) * 64 + (wave >> 2) * 32 + (wave & 1) * 16 + pt;
+  auto xform_item = [&](auto itc, float (&va)[4], float (&vb)[4]) {
+    constexpr int it = decltype(itc)::value;
+    const Raw& r = raw[it];
+    const float la = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r.qa.y), 0x111, 0xf, 0xf, true));
+    const float ra = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r.qa.x), 0x101, 0xf, 0xf, true));
+    const float lb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r.qb.y), 0x111, 0xf, 0xf, true));
+    const float rb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r.qb.x), 0x101, 0xf, 0xf, true));
+    const float a0 = pfirst ? r.ea : la, a3 = plast ? r.ea : ra;
+    const float b0 = pfirst ? r.eb : lb, b3 = plast ? r.eb : rb;
+    va[0] = a0 - r.qa.y; va[1] = r.qa.x + r.qa.y; va[2] = r.qa.y - r.qa.x; va[3] = r.qa.x - a3;
+    vb[0] = b0 - r.qb.y; vb[1] = r.qb.x + r.qb.y; vb[2] = r.qb.y - r.qb.x; vb[3] = r.qb.x - b3;
+  };
+  auto store_item = [&](unsigned* st, auto itc, const float (&va)[4], const float (&vb)[4], auto lo_c, auto hi_c) {
+    constexpr int it = decltype(itc)::value;
+    unsigned* vs = st + (it * 4 + rsub) * Y_RS + v_st;
+#pragma unroll
+    for (int x = decltype(lo_c)::value; x < decltype(hi_c)::value; ++x) {
+      unsigned hp, lp;
+      split2_pk_scaled(va[x], vb[x], hx_in, hp, lp);
+      vs[(x * 2 + 0) * 128] = hp;
+      vs[(x * 2 + 1) * 128] = lp;
+    }
+  };
+  auto stage_all = [&](unsigned* st) {
+    read_items();
+    static_for<3>([&](auto itc) {
+      float va[4], vb[4];
+      xform_item(itc, va, vb);
+      store_item(st, itc, va, vb, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+    });
+  };
+
+  // ---- consumer operands ----
+  const uint4* wq = reinterpret_cast<const uint4*>(a.wt);
+  const size_t pos_stride = (size_t)n_cc * n_ct * 128;
+  auto load_A = [&](uint4 (&fr)[2][2], int ky, int cc, int cob) {
+    const uint4* base = wq + (size_t)(ky * 4 + xi) * pos_stride + ((size_t)cc * n_ct + cob * 4 + chh * 2) * 128 + lane;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) fr[c][s] = base[c * 128 + s * 64];
+  };
+  const int b_lane = (j >> 4) * Y_RS + xi * 256 + h * 32 + (j & 15);
+  auto load_B = [&](uint4 (&fr)[2], const unsigned* cur, int r) {
+    const unsigned* bp = cur + r * Y_RS + b_lane;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) fr[s] = make_uint4(bp[s * 128], bp[s * 128 + 16], bp[s * 128 + 64], bp[s * 128 + 80]);
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) acc[i >> 2][i & 3][rr] = 0.f;
+
+  auto lds_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue of the first tile ----
+  Geo cur_g = geo_of(tile);
+  uint4 afr[2][2][2];
+  load_A(afr[0], 0, 0, cur_g.cob);
+  load_A(afr[1], 1, 0, cur_g.cob);
+  hx_scales_of(cur_g.b, hx_in, hx_out);
+  set_dma_geo(cur_g);
+  issue_dma(0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  stage_all(ldsw);
+  __syncthreads();
+  issue_dma(1);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+
+  if (a.dbg) t1 = tq = __builtin_amdgcn_s_memtime();
+  [[maybe_unused]] int pend_b = cur_g.b;
+  [[maybe_unused]] unsigned pend_o = 0u, pend_a = 0u;
+  auto flush_amax = [&]() {
+    if (lane == 0) {
+      if (a.amax_out) ipdm_amax_atomic(a.amax_out + (size_t)pend_b * IPDM_AMAX_SLOT, wave, __builtin_bit_cast(float, pend_o));
+      if (a.amax_act) ipdm_amax_atomic(a.amax_act + (size_t)pend_b * IPDM_AMAX_SLOT, wave, __builtin_bit_cast(float, pend_a));
+    }
+  };
+
+  while (true) {
+    const int next_tile = tile + S;
+    const bool has_next = next_tile < t_end;
+    const Geo next_g = geo_of(has_next ? next_tile : tile);
+    for (int ch2 = 0; ch2 < n_chunks; ch2 += 2) {
+      static_for<2>([&](auto cpc) {
+        constexpr int cpar = decltype(cpc)::value;
+        const int ch = ch2 + cpar;
+        const unsigned* cur = ldsw + cpar * Y_STAGE;
+        unsigned* nxt = ldsw + (1 - cpar) * Y_STAGE;
+        const bool dma_next = ch + 2 >= n_chunks;
+        const int dma_chunk = dma_next ? ch + 2 - n_chunks : ch + 2;
+        if (ch + 2 == n_chunks) set_dma_geo(next_g);
+        const bool a_next = ch + 1 >= n_chunks;                 // this chunk stages chunk 0 of the NEXT tile
+        const int a_chunk = a_next ? 0 : ch + 1;
+        const int a_cob = a_next ? next_g.cob : cur_g.cob;
+        if (a_next && next_g.b != cur_g.b) {
+          [[maybe_unused]] float unused_out;
+          hx_scales_of(next_g.b, hx_in, unused_out);
+        }
+        uint4 bsh[2][2];
+        // the wave's DMA of chunk ch+1 (issued a chunk ago) has landed: three fragment groups are younger, two of them still wanted
+        __builtin_amdgcn_s_waitcnt(0x0F78);                     // vmcnt(8)
+        read_items();
+        load_B(bsh[0], cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the raw rows are in registers
+        issue_dma(dma_chunk);
+        __builtin_amdgcn_sched_barrier(0);
+        float va[4], vb[4];
+        static_for<12>([&](auto ssc) {
+          constexpr int ss = decltype(ssc)::value;
+          constexpr int ky = ss >> 2, nb = ss & 3;
+          constexpr int aslot = (cpar * 3 + ky) & 1;
+          if constexpr (ss < 11) load_B(bsh[(ss + 1) & 1], cur, 2 * ((ss + 1) & 3) + ((ss + 1) >> 2));
+          // producer work of item ss / 4, dealt over the four sub-steps of a filter row
+          constexpr int it = ss >> 2;
+          if constexpr (nb == 0) xform_item(std::integral_constant<int, it>{}, va, vb);
+          if constexpr (nb == 1) store_item(nxt, std::integral_constant<int, it>{}, va, vb, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+          if constexpr (nb == 2) store_item(nxt, std::integral_constant<int, it>{}, va, vb, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+          const f16x8 bh = __builtin_bit_cast(f16x8, bsh[ss & 1][0]), bl = __builtin_bit_cast(f16x8, bsh[ss & 1][1]);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            f32x16 v = acc[c][nb];
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[aslot][c][1]), bh, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[aslot][c][0]), bl, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[aslot][c][0]), bh, v, 0, 0, 0);
+            acc[c][nb] = v;
+          }
+          if constexpr (nb == 3) {
+            // this filter row's fragments are free: request the row after next (same slot)
+            if constexpr (ky == 0) load_A(afr[aslot], 2, ch, cur_g.cob);
+            if constexpr (ky == 1) load_A(afr[aslot], 0, a_chunk, a_cob);
+            if constexpr (ky == 2) load_A(afr[aslot], 1, a_chunk, a_cob);
+          }
+          if constexpr (ss < 11) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // next sub-step's operand reads first
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+            if constexpr (nb == 1 || nb == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        lds_barrier();
+      });
+    }
+
+    if (a.dbg) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      t_loop += t - tq;
+      tq = t;
+    }
+    // ---- epilogue: eight rounds (channel tile c, column block nb) through M[xi][co 64][col 32] in stage 1 (last read) ----
+    float* ms = lds + Y_STAGE;
+    const int ecol = tid & 31, ecg = tid >> 5;                  // this thread: column, channels k*16 + ecg of the round's 64
+    const int co0 = cur_g.cob * Y_CO;
+    const float* const scale_p = reinterpret_cast<const float*>(wq + 12 * pos_stride);
+    const size_t tile_base = (((size_t)cur_g.b * a.Cout + co0) * HW + (size_t)cur_g.y0 * a.W + cur_g.x0) * 4;
+    unsigned eoff4 = 4u * (unsigned)(ecg * HW + (ecol >> 4) * a.W + 2 * (ecol & 15));
+    asm volatile("" : "+v"(eoff4));
+    auto boff = [&](int c, int nb, int k) -> unsigned {
+      return 4u * (unsigned)((((k >> 1) * 2 + c) * 32 + (k & 1) * 16) * HW + (2 * nb) * a.W) + eoff4;
+    };
+    auto in_range = [&](int nb) { return cur_g.y0 + 2 * nb + (ecol >> 4) < a.H && cur_g.x0 + 2 * (ecol & 15) < a.W; };
+    const bool has_res = a.residual != nullptr, has_bias = a.bias != nullptr;
+    const float* const res_p = has_res ? a.residual : a.wt;
+    const float* const bias_p = has_bias ? a.bias : a.wt;
+    const char* const res_b = reinterpret_cast<const char*>(res_p) + (has_res ? tile_base : 0);
+    char* const out_b = reinterpret_cast<char*>(a.out) + tile_base;
+    char* const act_b = reinterpret_cast<char*>(a.out_act) + tile_base;
+    float2 resv[2][4];
+    float biasv[2][4], scalev[2][4];
+    auto prefetch = [&](auto rc) {
+      constexpr int rnd = decltype(rc)::value;
+      constexpr int c = rnd >> 2, nb = rnd & 3, bf = rnd & 1;
+      const bool res_ok = has_res && in_range(nb);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int co = co0 + ((k >> 1) * 2 + c) * 32 + (k & 1) * 16 + ecg;
+        biasv[bf][k] = bias_p[has_bias ? cur_g.b * a.bias_bstride + co : 0];
+        scalev[bf][k] = scale_p[co] * hx_out;
+        const unsigned ob = res_ok ? boff(c, nb, k) : 0u;
+        resv[bf][k] = *reinterpret_cast<const float2*>(res_b + ob);
+      }
+    };
+    if (cur_g.b != pend_b) {
+      flush_amax();
+      pend_b = cur_g.b;
+      pend_o = pend_a = 0u;
+    }
+    prefetch(std::integral_constant<int, 0>{});
+    float amx_o = 0.f, amx_a = 0.f;
+    static_for<8>([&](auto rc) {
+      constexpr int rnd = decltype(rc)::value;
+      constexpr int c = rnd >> 2, nb = rnd & 3, bf = rnd & 1;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int col = (rr & 3) + 8 * (rr >> 2) + 4 * h;
+        ms[(xi * 64 + chh * 32 + col) * 32 + j] = acc[c][nb][rr];
+        acc[c][nb][rr] = 0.f;
+      }
+      __syncthreads();
+      if constexpr (rnd < 7) prefetch(std::integral_constant<int, rnd + 1>{});
+      [[maybe_unused]] float sv[4][2];
+      const bool inr = in_range(nb);
+      if (inr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int cl = k * 16 + ecg;
+          const float m0 = ms[(0 * 64 + cl) * 32 + ecol], m1 = ms[(1 * 64 + cl) * 32 + ecol];
+          const float m2 = ms[(2 * 64 + cl) * 32 + ecol], m3 = ms[(3 * 64 + cl) * 32 + ecol];
+          const float bias = has_bias ? biasv[bf][k] : 0.f;
+          float y0v = __builtin_fmaf(m0 + m1 + m2, scalev[bf][k], bias);
+          float y1v = __builtin_fmaf(m1 - m2 - m3, scalev[bf][k], bias);
+          const unsigned ob = boff(c, nb, k);
+          float r0v = y0v, r1v = y1v;
+          if (has_res) {
+            y0v += resv[bf][k].x;
+            y1v += resv[bf][k].y;
+          }
+          r0v = a.res_second ? r0v : y0v;
+          r1v = a.res_second ? r1v : y1v;
+          y0v *= a.out_scale;
+          y1v *= a.out_scale;
+          r0v *= a.out_scale;
+          r1v *= a.out_scale;
+          if constexpr (STATS) {
+            sv[k][0] = r0v;
+            sv[k][1] = r1v;
+          }
+          amx_o = fmaxf(amx_o, fmaxf(fabsf(r0v), fabsf(r1v)));
+          typedef float ntf2 __attribute__((ext_vector_type(2)));
+          if (a.out) __builtin_nontemporal_store(ntf2{r0v, r1v}, reinterpret_cast<ntf2*>(out_b + ob));
+          if (a.out_act) {
+            const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
+            const float e1 = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
+            amx_a = fmaxf(amx_a, fmaxf(fabsf(e0), fabsf(e1)));
+            *reinterpret_cast<float2*>(act_b + ob) = make_float2(e0, e1);
+          }
+        }
+      }
+      __syncthreads();
+    });
+    if (a.amax_out || a.amax_act) {
+      const unsigned mo = __builtin_bit_cast(unsigned, ipdm_wave_max(amx_o)), ma = __builtin_bit_cast(unsigned, ipdm_wave_max(amx_a));
+      const unsigned uo = __builtin_amdgcn_readfirstlane(mo), ua = __builtin_amdgcn_readfirstlane(ma);
+      pend_o = pend_o > uo ? pend_o : uo;
+      pend_a = pend_a > ua ? pend_a : ua;
+    }
+    if (a.dbg) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      t_epi += t - tq;
+      tq = t;
+    }
+    if (!has_next) break;
+    tile = next_tile;
+    if (next_g.b != cur_g.b) hx_scales_of(next_g.b, hx_in, hx_out);
+    cur_g = next_g;
+  }
+  flush_amax();
+  if (a.dbg && tid == 0) {
+    unsigned long long* d4 = a.dbg + (size_t)blockIdx.x * 4;
+    d4[0] = tq - t0; d4[1] = t1 - t0; d4[2] = t_loop; d4[3] = t_epi;
+  }
+}
+
+}  // namespace
+
+bool wino1d_ok(const ConvArgs& a) {
+  if (!(a.D == 1 && a.dil == 1 && a.Cin % (2 * Y_KC) == 0 && a.Cout % Y_CO == 0 && !a.coef && a.act == IPDM_ACT_NONE)) return false;
+  if ((size_t)a.B * a.Cin * a.H * a.W * 4 >= 0x3fffffffull) return false;
+  if (a.pool2 || a.stats) return false;
+  return a.H % 2 == 0 && a.W % 4 == 0 && a.H >= 8 && a.W >= 32 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
+}
+
+int conv_wino1d_launch(ConvArgs a, hipStream_t s) {
+  a.tiles_x = (a.W + 2 * Y_TX - 1) / (2 * Y_TX);
+  a.tiles_y = (a.H + Y_ROWS - 1) / Y_ROWS;
+  a.co_tiles = a.Cout / Y_CO;
+  const int64_t nblk = (int64_t)a.B * a.tiles_x * a.tiles_y * a.co_tiles;
+  if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino1d_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Y_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  int cus = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+    cus = 256;
+  const int per_xcd = (int)((nblk + 7) / 8);
+  const int S = per_xcd < cus / 8 ? per_xcd : cus / 8;
+  hipLaunchKernelGGL((conv_wino1d_kernel<false>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
+  return ipdm_launch_status();
+}
+
+int conv_wino1d_weights(const float* w, void* U, int Cout, int Cin, hipStream_t s) {
+  const int n_cc = (Cin + 15) / 16, n_ct = (Cout + 31) / 32;
+  const int64_t total = (int64_t)12 * n_cc * n_ct * 512;
+  float* inv_scale = reinterpret_cast<float*>(static_cast<char*>(U) + total * 2 * 2);
+  hipLaunchKernelGGL(wino1d_scale_kernel, dim3(n_ct * 32), dim3(256), 0, s, w, inv_scale, Cout, Cin, n_ct * 32);
+  hipLaunchKernelGGL(wino1d_weight_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, s, w, (unsigned short*)U, inv_scale, Cout,
+                     Cin, n_cc, n_ct);
+  return ipdm_launch_status();
+}
+
+}  // namespace ipdm_conv
+
+using namespace ipdm_conv;
+
+extern "C" int64_t ipdm_conv_wino1d_weight_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0) return -1;
+  return (int64_t)12 * ((Cin + 15) / 16) * ((Cout + 31) / 32) * 2048 + (int64_t)((Cout + 31) / 32) * 32 * 4;
+}
+
+extern "C" int ipdm_conv_wino1d_pack_weight(const float* w, void* U, int Cout, int Cin, void* stream) {
+  IPDM_REQUIRE(w && U && Cout > 0 && Cin > 0);
+  return conv_wino1d_weights(w, U, Cout, Cin, ipdm_stream(stream));
+}
+
+extern "C" int ipdm_conv2d_wino1d_supported(int Cin, int Cout, int H, int W) {
+  ConvArgs a;
+  a.x = nullptr; a.coef = nullptr; a.act = IPDM_ACT_NONE; a.dil = 1; a.D = 1; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.B = 1;
+  return wino1d_ok(a) ? 1 : 0;
+}
+
+extern "C" int ipdm_conv2d_wino1d_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
+                                      float* out_act, int act_out, int B, int Cin, int Cout, int H, int W,
+                                      const ipdm_conv_ext_t* ext, void* stream) {
+  IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && U && (out || out_act) && x != out && x != out_act);
+  ConvArgs a;
+  a.x = x; a.wt = (const float*)U; a.bias = bias; a.coef = nullptr; a.residual = residual; a.out = out; a.out_act = out_act;
+  a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = 1; a.act = IPDM_ACT_NONE;
+  a.D = 1; a.kd = 1; a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
+  a.hx = 1;
+  conv_apply_ext(a, ext, 1);
+  if (!wino1d_ok(a)) return IPDM_EUNSUPPORTED;
+  return conv_wino1d_launch(a, ipdm_stream(stream));
+}

@@ -83,6 +83,9 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
     def packed_wino_bx3(self):
         return self._cached("wino_" + ops.CONV_IMPL, ops.conv_wino_split_weight)
 
+    def packed_wino1d(self):
+        return self._cached("wino1d", ops.conv_wino1d_weight)
+
     def packed(self):
         if self.full_range and ops.CONV_IMPL == "hx2":
             return self._cached("direct_bx3", lambda w: ops.conv_weight(w, impl="bx3"))
@@ -115,9 +118,11 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
         if (USE_WINOGRAD and ops.split_impl() and self.ndim == 2 and self.kernel_size == 3 and coef is None
                 and act == ops.ACT_NONE and out is None and ops.wino_bx3_pays(self.in_planes, self.out_planes, x.shape[2],
                                                                               x.shape[3], self.dilation)):
-            return ops.conv2d_wino_bx3(x, self.packed_wino_bx3(), bias, residual, act_out=act_out, raw=raw,
-                                       dilation=self.dilation, want_stats=want_stats, in_amax=in_amax, want_amax=produce,
-                                       res_second=res_second)
+            one_d = (not (want_stats and raw and ops.USE_STATS_EPILOGUE) and x.data_ptr() % 16 == 0
+                     and ops.wino1d_pays(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation))
+            return ops.conv2d_wino_bx3(x, self.packed_wino1d() if one_d else self.packed_wino_bx3(), bias, residual,
+                                       act_out=act_out, raw=raw, dilation=self.dilation, want_stats=want_stats, in_amax=in_amax,
+                                       want_amax=produce, res_second=res_second)
         if self.ndim == 3:
             return ops.conv3d(x, self.packed(), bias, coef, act, residual, self.dilation, act_out=act_out, raw=raw,
                               in_amax=in_amax, want_amax=produce, res_second=res_second)

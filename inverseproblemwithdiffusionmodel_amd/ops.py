@@ -1183,6 +1183,25 @@ def conv_wino_hx2_weight(w):
     return conv_wino_bx3_weight(w, fmt="hx2")
 
 
+def conv_wino1d_weight(w):
+    """[Cout, Cin, 3, 3] -> weights of the 1-D Winograd kernel (F(2,3) along x, the filter's rows as K; f16x2 pieces; PackedBx3, kk=12)"""
+    w = _gpu(w, torch.float32, "weight")
+    Cout, Cin = w.shape[:2]
+    blob = torch.empty(_lib.lib.ipdm_conv_wino1d_weight_bytes(Cout, Cin), dtype=torch.uint8, device=w.device)
+    call("ipdm_conv_wino1d_pack_weight", _ptr(w), _ptr(blob), Cout, Cin, _stream())
+    return PackedBx3(blob, Cout, Cin, 12, "hx2")
+
+
+WINO1D = os.environ.get("IPDM_WINO1D", "0") != "0"
+
+
+def wino1d_pays(Cin, Cout, H, W, dilation=1):
+    """layers the 1-D Winograd kernel takes from the 2-D one (a function of the layer SHAPE only): f16x2 family, undilated,
+    at least 128 output channels in blocks of 128, rows of 32 pixels or more"""
+    return (WINO1D and CONV_IMPL == "hx2" and dilation == 1
+            and bool(_lib.lib.ipdm_conv2d_wino1d_supported(int(Cin), int(Cout), int(H), int(W))))
+
+
 def conv_wino_split_weight(w, impl=None):
     """Winograd-domain weights for the selected split family (CONV_IMPL = "hx2" / "bx3")"""
     impl = CONV_IMPL if impl is None else impl
@@ -1221,8 +1240,11 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
 
     def bias_of(b0, b1):
         return bias[b0:b1] if bias_per_image else bias
-    if U.kk != 16 or U.Cin != Cin:
+    one_d = U.kk == 12                   # conv_wino1d_weight: 1-D Winograd along x (conv_wino1d.hip), plain epilogues only
+    if U.kk not in (12, 16) or U.Cin != Cin:
         raise ValueError("conv2d_wino_bx3: weight blob does not match the input")
+    if one_d and (pool2 or dilation != 1 or U.fmt != "hx2"):
+        raise ValueError("conv2d_wino_bx3: the 1-D Winograd blob serves undilated, unpooled f16x2 launches only")
     if res_second and (residual is None or act_out == ACT_NONE or not raw):
         raise ValueError("conv2d_wino_bx3: res_second needs a residual and both outputs (act_out, e.g. ACT_COPY; raw=True)")
     Cout = U.Cout
@@ -1236,7 +1258,7 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     nb = wino_bx3_max_batch(Cin, H, W, dilation)
-    ksplit = 1 if pool2 or x.data_ptr() % 16 else wino_bx3_splitk(Cin, Cout, H, W, dilation)
+    ksplit = 1 if one_d or pool2 or x.data_ptr() % 16 else wino_bx3_splitk(Cin, Cout, H, W, dilation)
     if ksplit > 1:                       # 16-pixel layers with few channel tiles: two K halves + a fixed-order reduction
         for b0 in range(0, B, nb):
             b1 = min(B, b0 + nb)
@@ -1253,7 +1275,7 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
         tag_amax(out_act, slot_a)
         return (out, out_act) if want_act else out
     part = None
-    if want_stats and raw and USE_STATS_EPILOGUE and x.data_ptr() % 16 == 0:
+    if want_stats and raw and USE_STATS_EPILOGUE and x.data_ptr() % 16 == 0 and not one_d:
         P = int(_lib.lib.ipdm_conv2d_wino_bx3_stats_partials(Cin, Cout, H, W, dilation, int(bool(pool2))))
         if P > 0:
             part = torch.empty((B, Cout, P, 3), dtype=torch.float32, device=x.device)
@@ -1264,6 +1286,9 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
                 _ptr(None if out_act is None else out_act[b0:b1]), act_out, b1 - b0, Cin, Cout, H, W, dilation,
                 int(bool(pool2)))
         am = (ext_of(b0, b1),)
+        if one_d:
+            call("ipdm_conv2d_wino1d_f32", *args[:-2], *am, _stream())
+            continue
         if part is not None:
             try:
                 call(f"ipdm_conv2d_wino_{U.fmt}_stats_f32", *args, _ptr(part[b0:b1]), *am, _stream())
@@ -1276,7 +1301,7 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
     if CONV_TRACE is not None:
         e1.record()
         CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, fmt=U.fmt, res=residual is not None,
-                               n_out=int(raw) + int(want_act), pool2=bool(pool2), e0=e0, e1=e1))
+                               n_out=int(raw) + int(want_act), pool2=bool(pool2), wino1d=one_d, e0=e0, e1=e1))
     tag_amax(out, slot_o)
     tag_amax(out_act, slot_a)
     return (out, out_act) if want_act else out
