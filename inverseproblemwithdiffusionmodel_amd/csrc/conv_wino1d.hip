@@ -17,7 +17,8 @@
 //   B (V = B^T d, rows): raw rows by wave-private 16-byte LDS-DMA exactly as the 2-D kernel's (same 10 x 40 region per
 //        channel), transformed along x, split once into packed fp16 pairs and stored as
 //        Vs[row 12][xi 4][piece 2][q>>1][h][q&1][tile 16] words (channel pair cp = 4h + q); a staged row serves three filter rows.
-// Two 48.75 KiB V stages + 32 KiB raw; the epilogue's exchange buffer M[xi 4][co 64][col 32] overlays the stage last read.
+// Two 48.75 KiB V stages + 32 KiB raw; the epilogue's two exchange buffers M[xi 4][co 64][col 32] overlay the stage last read and
+// the 15 KiB behind it (one barrier per round: a round's stores go to the buffer the previous round did not read).
 // Eligible: 3x3, dilation 1, Cin % 32 == 0, Cout % 128 == 0, W % 4 == 0, 16-byte aligned input (launcher).
 #include "conv_kernel.h"
 
@@ -32,10 +33,13 @@ constexpr int Y_VROWS = 12;                          // 10 staged rows + 2 that 
 constexpr int Y_RS = 1040;                           // words per staged row: 16 (xi, piece, q>>1) x 64 + 16 (bank offset of a row)
 constexpr int Y_STAGE = Y_VROWS * Y_RS;              // 12480 words
 constexpr int Y_RAW = 8 * 1024;                      // eight wave-private 4 KiB blocks
-constexpr size_t Y_LDS_BYTES = (2 * (size_t)Y_STAGE + Y_RAW) * 4;
+constexpr int Y_M = 4 * 64 * 32;                     // floats of one exchange buffer M[xi 4][co 64][col 32]
+// LDS: V stage 0 | raw stage | V stage 1 = exchange buffer 0, then exchange buffer 1 (its tail lies behind stage 1)
+constexpr int Y_S1 = Y_STAGE + Y_RAW;                // word offset of stage 1
+constexpr size_t Y_LDS_BYTES = ((size_t)Y_S1 + 2 * Y_M + 2 * Y_CO) * 4;   // + the epilogue's (scale, bias) table
+static_assert(Y_STAGE <= 2 * Y_M && Y_LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr float HX1_PRESCALE = 0.5f;                 // the 1-D input transform at most doubles a value
 constexpr int Y_QC = 10, Y_RC4 = 40, Y_QN = 100;     // quads / floats per raw row, quads per channel
-static_assert(4 * 64 * 32 <= Y_STAGE, "the exchange buffer fits a V stage");
 
 __device__ __forceinline__ float wino1d_U(const float* g, int p) {       // p = ky*4 + xi
   const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void wino1d_weight_kernel(const float* __restr
   }
 }
 
-template <bool STATS>
+template <int OUTS>                                 // 1: out, 2: out_act, 3: both (the launcher picks; no branch per store)
 __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_tiles) {
   extern __shared__ __align__(16) float lds[];
   unsigned* const ldsw = reinterpret_cast<unsigned*>(lds);
@@ -99,6 +103,9 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
   const int n_cc = a.Cin / Y_KC, n_ct = a.Cout / 32;
   const int n_chunks = n_cc;                                   // even, >= 2 (launcher)
   unsigned long long t0 = 0, t1 = 0, t_loop = 0, t_epi = 0, tq = 0;   // tuning stamps (a.dbg)
+#ifdef IPDM_W1D_TRACE
+  unsigned long long te[4] = {0, 0, 0, 0};                            // epilogue phases: exchange stores, barrier, transform + stores, barrier
+#endif
   if (a.dbg) t0 = __builtin_amdgcn_s_memtime();
 
   // ---- this workgroup's tile list (XCD-aware, as conv_wino_bx3_wide_kernel) ----
@@ -109,6 +116,12 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
   const int t_end = x_start + q8 + (xcd < r8 ? 1 : 0);
   int tile = x_start + slot;
   if (tile >= t_end) return;
+  // phase groups (tuning, IPDM_W1D_STAGGER): group slot % 4 starts g * stagger cycles late, so that the workgroups' epilogues -- all
+  // 256 hit HBM in the same microseconds otherwise -- are spread over the pass
+  if (a.ksplit > 1) {
+    const int g = slot & 3;
+    for (int i = 0; i < g * (a.ksplit - 1); ++i) __builtin_amdgcn_s_sleep(8);          // ~8 x 64 cycles each
+  }
 
   struct Geo { int b, y0, x0, cob; };
   auto geo_of = [&](int L) {
@@ -125,7 +138,7 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
 
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.x), 0, (int)((size_t)a.B * a.Cin * HW * 4), 0x00020000);
-  float* const rs = lds + 2 * Y_STAGE;
+  float* const rs = lds + Y_STAGE;
 
   // raw stage: wave w fetches channels 2w, 2w+1 of a chunk (2 x 100 quads) into its own block, four 16-byte LDS-DMA instructions
   int dma_off[4];
@@ -280,8 +293,8 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
       static_for<2>([&](auto cpc) {
         constexpr int cpar = decltype(cpc)::value;
         const int ch = ch2 + cpar;
-        const unsigned* cur = ldsw + cpar * Y_STAGE;
-        unsigned* nxt = ldsw + (1 - cpar) * Y_STAGE;
+        const unsigned* cur = ldsw + cpar * Y_S1;
+        unsigned* nxt = ldsw + (1 - cpar) * Y_S1;
         const bool dma_next = ch + 2 >= n_chunks;
         const int dma_chunk = dma_next ? ch + 2 - n_chunks : ch + 2;
         if (ch + 2 == n_chunks) set_dma_geo(next_g);
@@ -345,8 +358,9 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
       t_loop += t - tq;
       tq = t;
     }
-    // ---- epilogue: eight rounds (channel tile c, column block nb) through M[xi][co 64][col 32] in stage 1 (last read) ----
-    float* ms = lds + Y_STAGE;
+    // ---- epilogue: eight rounds (channel tile c, column block nb) through M[rnd & 1][xi][co 64][col 32] ----
+    constexpr bool W_OUT = (OUTS & 1) != 0, W_ACT = (OUTS & 2) != 0;
+    float* const ms = lds + Y_S1;
     const int ecol = tid & 31, ecg = tid >> 5;                  // this thread: column, channels k*16 + ecg of the round's 64
     const int co0 = cur_g.cob * Y_CO;
     const float* const scale_p = reinterpret_cast<const float*>(wq + 12 * pos_stride);
@@ -358,22 +372,20 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
     };
     auto in_range = [&](int nb) { return cur_g.y0 + 2 * nb + (ecol >> 4) < a.H && cur_g.x0 + 2 * (ecol & 15) < a.W; };
     const bool has_res = a.residual != nullptr, has_bias = a.bias != nullptr;
+    const bool elu = a.act_out == IPDM_ACT_ELU;                 // otherwise the activated copy is the identity (launcher)
     const float* const res_p = has_res ? a.residual : a.wt;
     const float* const bias_p = has_bias ? a.bias : a.wt;
     const char* const res_b = reinterpret_cast<const char*>(res_p) + (has_res ? tile_base : 0);
-    char* const out_b = reinterpret_cast<char*>(a.out) + tile_base;
-    char* const act_b = reinterpret_cast<char*>(a.out_act) + tile_base;
+    [[maybe_unused]] char* const out_b = reinterpret_cast<char*>(a.out) + tile_base;
+    [[maybe_unused]] char* const act_b = reinterpret_cast<char*>(a.out_act) + tile_base;
     float2 resv[2][4];
-    float biasv[2][4], scalev[2][4];
+    // (unconditional loads -- an absent operand or an out-of-range column reads the weight blob -- so that hipcc can count them)
     auto prefetch = [&](auto rc) {
       constexpr int rnd = decltype(rc)::value;
       constexpr int c = rnd >> 2, nb = rnd & 3, bf = rnd & 1;
       const bool res_ok = has_res && in_range(nb);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int co = co0 + ((k >> 1) * 2 + c) * 32 + (k & 1) * 16 + ecg;
-        biasv[bf][k] = bias_p[has_bias ? cur_g.b * a.bias_bstride + co : 0];
-        scalev[bf][k] = scale_p[co] * hx_out;
         const unsigned ob = res_ok ? boff(c, nb, k) : 0u;
         resv[bf][k] = *reinterpret_cast<const float2*>(res_b + ob);
       }
@@ -383,59 +395,85 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
       pend_b = cur_g.b;
       pend_o = pend_a = 0u;
     }
+    // this pass's 128 (scale, bias) pairs go through a small LDS table: as vector loads prefetched a round ahead they held 16
+    // registers through the whole epilogue
+    float* const es = lds + Y_S1 + 2 * Y_M;
+    if (tid < Y_CO) {
+      es[tid] = scale_p[co0 + tid] * hx_out;
+      es[Y_CO + tid] = has_bias ? bias_p[cur_g.b * a.bias_bstride + co0 + tid] : 0.f;
+    }
     prefetch(std::integral_constant<int, 0>{});
     float amx_o = 0.f, amx_a = 0.f;
+#ifdef IPDM_W1D_TRACE
+#define W1D_TE(k) if (a.dbg) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te[k] += t_ - tl; tl = t_; }
+    unsigned long long tl = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
+#else
+#define W1D_TE(k)
+#endif
     static_for<8>([&](auto rc) {
       constexpr int rnd = decltype(rc)::value;
       constexpr int c = rnd >> 2, nb = rnd & 3, bf = rnd & 1;
+      float* const mw = ms + (rnd & 1) * Y_M;
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) {
         const int col = (rr & 3) + 8 * (rr >> 2) + 4 * h;
-        ms[(xi * 64 + chh * 32 + col) * 32 + j] = acc[c][nb][rr];
+        mw[(xi * 64 + chh * 32 + col) * 32 + j] = acc[c][nb][rr];
         acc[c][nb][rr] = 0.f;
       }
+      W1D_TE(0);
       __syncthreads();
+      W1D_TE(1);
       if constexpr (rnd < 7) prefetch(std::integral_constant<int, rnd + 1>{});
-      [[maybe_unused]] float sv[4][2];
       const bool inr = in_range(nb);
-      if (inr) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int cl = k * 16 + ecg;
-          const float m0 = ms[(0 * 64 + cl) * 32 + ecol], m1 = ms[(1 * 64 + cl) * 32 + ecol];
-          const float m2 = ms[(2 * 64 + cl) * 32 + ecol], m3 = ms[(3 * 64 + cl) * 32 + ecol];
-          const float bias = has_bias ? biasv[bf][k] : 0.f;
-          float y0v = __builtin_fmaf(m0 + m1 + m2, scalev[bf][k], bias);
-          float y1v = __builtin_fmaf(m1 - m2 - m3, scalev[bf][k], bias);
-          const unsigned ob = boff(c, nb, k);
+      for (int half = 0; half < 2; ++half) {
+        float m[2][4], sc[2], bi[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int k = half * 2 + kk;
+          const int cidx = ((k >> 1) * 2 + c) * 32 + (k & 1) * 16 + ecg;
+          sc[kk] = es[cidx];
+          bi[kk] = es[Y_CO + cidx];
+#pragma unroll
+          for (int x = 0; x < 4; ++x) m[kk][x] = mw[(x * 64 + k * 16 + ecg) * 32 + ecol];
+        }
+        float2 ov[2], ev[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int k = half * 2 + kk;
+          float y0v = __builtin_fmaf(m[kk][0] + m[kk][1] + m[kk][2], sc[kk], bi[kk]);
+          float y1v = __builtin_fmaf(m[kk][1] - m[kk][2] - m[kk][3], sc[kk], bi[kk]);
           float r0v = y0v, r1v = y1v;
-          if (has_res) {
-            y0v += resv[bf][k].x;
-            y1v += resv[bf][k].y;
-          }
+          y0v += has_res ? resv[bf][k].x : 0.f;
+          y1v += has_res ? resv[bf][k].y : 0.f;
           r0v = a.res_second ? r0v : y0v;
           r1v = a.res_second ? r1v : y1v;
           y0v *= a.out_scale;
           y1v *= a.out_scale;
           r0v *= a.out_scale;
           r1v *= a.out_scale;
-          if constexpr (STATS) {
-            sv[k][0] = r0v;
-            sv[k][1] = r1v;
+          ov[kk] = make_float2(r0v, r1v);
+          if constexpr (W_OUT) amx_o = fmaxf(amx_o, inr ? fmaxf(fabsf(r0v), fabsf(r1v)) : 0.f);
+          if constexpr (W_ACT) {
+            const float e0 = elu ? fast_elu(y0v) : y0v, e1 = elu ? fast_elu(y1v) : y1v;
+            ev[kk] = make_float2(e0, e1);
+            amx_a = fmaxf(amx_a, inr ? fmaxf(fabsf(e0), fabsf(e1)) : 0.f);
           }
-          amx_o = fmaxf(amx_o, fmaxf(fabsf(r0v), fabsf(r1v)));
-          typedef float ntf2 __attribute__((ext_vector_type(2)));
-          if (a.out) __builtin_nontemporal_store(ntf2{r0v, r1v}, reinterpret_cast<ntf2*>(out_b + ob));
-          if (a.out_act) {
-            const float e0 = a.act_out == IPDM_ACT_ELU ? fast_elu(y0v) : ipdm_act(y0v, a.act_out);
-            const float e1 = a.act_out == IPDM_ACT_ELU ? fast_elu(y1v) : ipdm_act(y1v, a.act_out);
-            amx_a = fmaxf(amx_a, fmaxf(fabsf(e0), fabsf(e1)));
-            *reinterpret_cast<float2*>(act_b + ob) = make_float2(e0, e1);
+        }
+        if (inr) {
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const unsigned ob = boff(c, nb, half * 2 + kk);
+            typedef float ntf2 __attribute__((ext_vector_type(2)));
+            if constexpr (W_OUT) __builtin_nontemporal_store(ntf2{ov[kk].x, ov[kk].y}, reinterpret_cast<ntf2*>(out_b + ob));
+            if constexpr (W_ACT) *reinterpret_cast<float2*>(act_b + ob) = ev[kk];
           }
         }
       }
-      __syncthreads();
+      W1D_TE(2);
     });
+    __syncthreads();                                            // the next tile's second chunk is staged over the exchange buffers
+    W1D_TE(3);
     if (a.amax_out || a.amax_act) {
       const unsigned mo = __builtin_bit_cast(unsigned, ipdm_wave_max(amx_o)), ma = __builtin_bit_cast(unsigned, ipdm_wave_max(amx_a));
       const unsigned uo = __builtin_amdgcn_readfirstlane(mo), ua = __builtin_amdgcn_readfirstlane(ma);
@@ -456,6 +494,10 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
   if (a.dbg && tid == 0) {
     unsigned long long* d4 = a.dbg + (size_t)blockIdx.x * 4;
     d4[0] = tq - t0; d4[1] = t1 - t0; d4[2] = t_loop; d4[3] = t_epi;
+#ifdef IPDM_W1D_TRACE
+    unsigned long long* d8 = a.dbg + (size_t)gridDim.x * 4 + (size_t)blockIdx.x * 4;
+    d8[0] = te[0]; d8[1] = te[1]; d8[2] = te[2]; d8[3] = te[3];
+#endif
   }
 }
 
@@ -463,12 +505,19 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
 
 bool wino1d_ok(const ConvArgs& a) {
   if (!(a.D == 1 && a.dil == 1 && a.Cin % (2 * Y_KC) == 0 && a.Cout % Y_CO == 0 && !a.coef && a.act == IPDM_ACT_NONE)) return false;
+  if (a.out_act && a.act_out != IPDM_ACT_ELU && a.act_out != IPDM_ACT_COPY) return false;    // the epilogue's branch-free activations
   if ((size_t)a.B * a.Cin * a.H * a.W * 4 >= 0x3fffffffull) return false;
   if (a.pool2 || a.stats) return false;
   return a.H % 2 == 0 && a.W % 4 == 0 && a.H >= 8 && a.W >= 32 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
 }
 
 int conv_wino1d_launch(ConvArgs a, hipStream_t s) {
+  static int stagger = -1;                       // IPDM_W1D_STAGGER=<cycles>: start delay per phase group (tuning)
+  if (stagger < 0) {
+    const char* e = getenv("IPDM_W1D_STAGGER");
+    stagger = e ? atoi(e) / 512 : 0;
+  }
+  a.ksplit = stagger > 0 ? stagger + 1 : 1;
   a.tiles_x = (a.W + 2 * Y_TX - 1) / (2 * Y_TX);
   a.tiles_y = (a.H + Y_ROWS - 1) / Y_ROWS;
   a.co_tiles = a.Cout / Y_CO;
@@ -476,9 +525,12 @@ int conv_wino1d_launch(ConvArgs a, hipStream_t s) {
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino1d_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Y_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
+    const void* kernels[] = {reinterpret_cast<const void*>(conv_wino1d_kernel<1>), reinterpret_cast<const void*>(conv_wino1d_kernel<2>),
+                             reinterpret_cast<const void*>(conv_wino1d_kernel<3>)};
+    for (const void* k : kernels) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Y_LDS_BYTES);
+      if (e != hipSuccess) return (int)e;
+    }
     attr_set = true;
   }
   int cus = 0, dev = 0;
@@ -486,7 +538,12 @@ int conv_wino1d_launch(ConvArgs a, hipStream_t s) {
     cus = 256;
   const int per_xcd = (int)((nblk + 7) / 8);
   const int S = per_xcd < cus / 8 ? per_xcd : cus / 8;
-  hipLaunchKernelGGL((conv_wino1d_kernel<false>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
+  if (a.out && a.out_act)
+    hipLaunchKernelGGL((conv_wino1d_kernel<3>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
+  else if (a.out)
+    hipLaunchKernelGGL((conv_wino1d_kernel<1>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
+  else
+    hipLaunchKernelGGL((conv_wino1d_kernel<2>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
   return ipdm_launch_status();
 }
 
@@ -516,7 +573,7 @@ extern "C" int ipdm_conv_wino1d_pack_weight(const float* w, void* U, int Cout, i
 
 extern "C" int ipdm_conv2d_wino1d_supported(int Cin, int Cout, int H, int W) {
   ConvArgs a;
-  a.x = nullptr; a.coef = nullptr; a.act = IPDM_ACT_NONE; a.dil = 1; a.D = 1; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.B = 1;
+  a.x = nullptr; a.out = a.out_act = nullptr; a.act_out = IPDM_ACT_NONE; a.coef = nullptr; a.act = IPDM_ACT_NONE; a.dil = 1; a.D = 1; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.B = 1;
   return wino1d_ok(a) ? 1 : 0;
 }
 

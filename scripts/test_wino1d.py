@@ -98,6 +98,9 @@ if __name__ == "__main__":
     check(2, 64, 128, 16, 64)
     check(3, 128, 256, 40, 36)
     check(2, 128, 128, 128, 128)
+    if "--bench1" in sys.argv:
+        bench(28, 128, 128, 128, 128)
+        bench(28, 256, 256, 64, 64)
     if "--bench" in sys.argv:
         bench(28, 128, 128, 128, 128)
         bench(28, 256, 256, 64, 64)

@@ -23,8 +23,12 @@ for ci, co, hw, (vn, use_r, act) in [(128, 128, 128, v) for v in VAR] + [(256, 2
     _lib.lib.ipdm_debug_set_stamp_buffer(_lib.P(0))
     t = buf.cpu()[:256 * 4].view(-1, 4).double()
     t = t[t[:, 0] != 0]
+    te = buf.cpu()[256 * 4:256 * 8].view(-1, 4).double()
     tiles = B * (hw // 8) * (hw // 32) * (co // 128) / t.shape[0]
     nch = ci // 16
     print(f"{ci}->{co}@{hw} {vn:8s}: {ms * 1e3:.0f} us; {t.shape[0]} WGs x {tiles:.2f} passes; cycles total median {t[:, 0].median():.0f} max {t[:, 0].max():.0f} "
           f"(clock {t[:, 0].max() / ms / 1e6:.2f} GHz); prologue {t[:, 1].median():.0f}; per pass: loop {t[:, 2].median() / tiles:.0f} "
           f"= {t[:, 2].median() / tiles / nch:.0f} per chunk (MFMA floor 4608), epilogue {t[:, 3].median() / tiles:.0f}", flush=True)
+    if te.abs().sum() > 0:
+        m = te.median(0).values / tiles / 8
+        print(f"      per round (wave 0): exchange stores {m[0]:.0f}, barrier {m[1]:.0f}, transform + stores {m[2]:.0f}, barrier {m[3]:.0f}", flush=True)
