@@ -454,6 +454,12 @@ int ipdm_conv2d_wino1d_supported(int Cin, int Cout, int H, int W);
 int ipdm_conv2d_wino1d_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
                            float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, const ipdm_conv_ext_t* ext,
                            void* stream);
+/* ... with the statistics epilogue (as ipdm_conv2d_wino_hx2_stats_f32): stats[B][Cout][P][3] = (count, mean, sum of squared
+ * deviations) of `out` per 8 x 32 pixel block, P = ipdm_conv2d_wino1d_stats_partials (0: not served) */
+int ipdm_conv2d_wino1d_stats_partials(int Cin, int Cout, int H, int W);
+int ipdm_conv2d_wino1d_stats_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
+                                 float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, float* stats,
+                                 const ipdm_conv_ext_t* ext, void* stream);
 int ipdm_conv2d_wino_hx2_splitk_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
                                     float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
                                     int ksplit, float* work, const ipdm_conv_ext_t* ext, void* stream);

@@ -104,6 +104,17 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// sum over the 32 lanes of a half-wave, the total in every lane: four DPP adds inside the 16-lane rows (quad swaps, then the
+// half-row and row mirrors) and one cross-row exchange -- a fixed order, and a fifth of the latency of five bpermutes
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
+  return v + __shfl_xor(v, 16, 64);
+}
+
+
 struct ConvArgs {
   const float* x;
   const float* wt;

@@ -90,7 +90,10 @@ __global__ __launch_bounds__(256) void wino1d_weight_kernel(const float* __restr
   }
 }
 
-template <int OUTS>                                 // 1: out, 2: out_act, 3: both (the launcher picks; no branch per store)
+// OUTS 1: out, 2: out_act, 3: both (the launcher picks; no branch per store).  STATS: per (image, channel, pixel block) the stored `out`
+// values are reduced to (count, mean, sum of squared deviations) partials [B][Cout][tiles_y * tiles_x][3] for the InstanceNorm++
+// that follows (deterministic: fixed butterflies inside a half-wave, the four rounds of a channel tile accumulated in registers)
+template <int OUTS, bool STATS = false>
 __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_tiles) {
   extern __shared__ __align__(16) float lds[];
   unsigned* const ldsw = reinterpret_cast<unsigned*>(lds);
@@ -404,6 +407,8 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
     }
     prefetch(std::integral_constant<int, 0>{});
     float amx_o = 0.f, amx_a = 0.f;
+    [[maybe_unused]] float st_k[4], st_s1[4], st_s2[4];          // STATS: shift, sum (v - K), sum (v - K)^2 of this thread's four channels
+    [[maybe_unused]] int st_c0 = 0, st_c1 = 0;                   //        in-range values of the two half-waves
 #ifdef IPDM_W1D_TRACE
 #define W1D_TE(k) if (a.dbg) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te[k] += t_ - tl; tl = t_; }
     unsigned long long tl = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
@@ -453,6 +458,19 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
           r0v *= a.out_scale;
           r1v *= a.out_scale;
           ov[kk] = make_float2(r0v, r1v);
+          if constexpr (STATS) {
+            if constexpr (nb == 0) {
+              // the shift K is taken FROM the data (the half-wave's first value of the channel tile's first round), so that the
+              // subtraction below cancels nothing the spread of the data does not
+              const float k0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r0v), 0));
+              const float k1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r0v), 32));
+              st_k[k] = h ? k1 : k0;
+              st_s1[k] = st_s2[k] = 0.f;
+            }
+            const float d0 = inr ? r0v - st_k[k] : 0.f, d1 = inr ? r1v - st_k[k] : 0.f;
+            st_s1[k] += d0 + d1;
+            st_s2[k] = __builtin_fmaf(d0, d0, __builtin_fmaf(d1, d1, st_s2[k]));
+          }
           if constexpr (W_OUT) amx_o = fmaxf(amx_o, inr ? fmaxf(fabsf(r0v), fabsf(r1v)) : 0.f);
           if constexpr (W_ACT) {
             const float e0 = elu ? fast_elu(y0v) : y0v, e1 = elu ? fast_elu(y1v) : y1v;
@@ -467,6 +485,27 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
             typedef float ntf2 __attribute__((ext_vector_type(2)));
             if constexpr (W_OUT) __builtin_nontemporal_store(ntf2{ov[kk].x, ov[kk].y}, reinterpret_cast<ntf2*>(out_b + ob));
             if constexpr (W_ACT) *reinterpret_cast<float2*>(act_b + ob) = ev[kk];
+          }
+        }
+      }
+      if constexpr (STATS) {
+        const unsigned long long bal = __ballot(inr);
+        if constexpr (nb == 0) st_c0 = st_c1 = 0;
+        st_c0 += 2 * __popcll(bal & 0xffffffffull);
+        st_c1 += 2 * __popcll(bal >> 32);
+        if constexpr (nb == 3) {
+          const float cnt = (float)(h ? st_c1 : st_c0);
+          const int tb = (cur_g.y0 / Y_ROWS) * a.tiles_x + cur_g.x0 / (2 * Y_TX);
+          const int n_tb = a.tiles_x * a.tiles_y;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float s1 = half_wave_sum(st_s1[k]), s2 = half_wave_sum(st_s2[k]);
+            if (ecol == 0) {
+              const int co = co0 + ((k >> 1) * 2 + c) * 32 + (k & 1) * 16 + ecg;
+              float* sp = a.stats + (((size_t)cur_g.b * a.Cout + co) * n_tb + tb) * 3;
+              const float dm = cnt > 0.f ? s1 / cnt : 0.f;
+              sp[0] = cnt; sp[1] = st_k[k] + dm; sp[2] = fmaxf(s2 - s1 * dm, 0.f);
+            }
           }
         }
       }
@@ -507,7 +546,8 @@ bool wino1d_ok(const ConvArgs& a) {
   if (!(a.D == 1 && a.dil == 1 && a.Cin % (2 * Y_KC) == 0 && a.Cout % Y_CO == 0 && !a.coef && a.act == IPDM_ACT_NONE)) return false;
   if (a.out_act && a.act_out != IPDM_ACT_ELU && a.act_out != IPDM_ACT_COPY) return false;    // the epilogue's branch-free activations
   if ((size_t)a.B * a.Cin * a.H * a.W * 4 >= 0x3fffffffull) return false;
-  if (a.pool2 || a.stats) return false;
+  if (a.pool2) return false;
+  if (a.stats && !a.out) return false;
   return a.H % 2 == 0 && a.W % 4 == 0 && a.H >= 8 && a.W >= 32 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
 }
 
@@ -526,7 +566,8 @@ int conv_wino1d_launch(ConvArgs a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     const void* kernels[] = {reinterpret_cast<const void*>(conv_wino1d_kernel<1>), reinterpret_cast<const void*>(conv_wino1d_kernel<2>),
-                             reinterpret_cast<const void*>(conv_wino1d_kernel<3>)};
+                             reinterpret_cast<const void*>(conv_wino1d_kernel<3>), reinterpret_cast<const void*>(conv_wino1d_kernel<1, true>),
+                             reinterpret_cast<const void*>(conv_wino1d_kernel<3, true>)};
     for (const void* k : kernels) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Y_LDS_BYTES);
       if (e != hipSuccess) return (int)e;
@@ -538,7 +579,11 @@ int conv_wino1d_launch(ConvArgs a, hipStream_t s) {
     cus = 256;
   const int per_xcd = (int)((nblk + 7) / 8);
   const int S = per_xcd < cus / 8 ? per_xcd : cus / 8;
-  if (a.out && a.out_act)
+  if (a.stats && a.out_act)
+    hipLaunchKernelGGL((conv_wino1d_kernel<3, true>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
+  else if (a.stats)
+    hipLaunchKernelGGL((conv_wino1d_kernel<1, true>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
+  else if (a.out && a.out_act)
     hipLaunchKernelGGL((conv_wino1d_kernel<3>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
   else if (a.out)
     hipLaunchKernelGGL((conv_wino1d_kernel<1>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
@@ -577,9 +622,8 @@ extern "C" int ipdm_conv2d_wino1d_supported(int Cin, int Cout, int H, int W) {
   return wino1d_ok(a) ? 1 : 0;
 }
 
-extern "C" int ipdm_conv2d_wino1d_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
-                                      float* out_act, int act_out, int B, int Cin, int Cout, int H, int W,
-                                      const ipdm_conv_ext_t* ext, void* stream) {
+static int wino1d_entry(const float* x, const void* U, const float* bias, const float* residual, float* out, float* out_act,
+                        int act_out, int B, int Cin, int Cout, int H, int W, float* stats, const ipdm_conv_ext_t* ext, void* stream) {
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && U && (out || out_act) && x != out && x != out_act);
@@ -588,7 +632,27 @@ extern "C" int ipdm_conv2d_wino1d_f32(const float* x, const void* U, const float
   a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = 1; a.act = IPDM_ACT_NONE;
   a.D = 1; a.kd = 1; a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
   a.hx = 1;
+  a.stats = stats;
   conv_apply_ext(a, ext, 1);
   if (!wino1d_ok(a)) return IPDM_EUNSUPPORTED;
   return conv_wino1d_launch(a, ipdm_stream(stream));
+}
+
+extern "C" int ipdm_conv2d_wino1d_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
+                                      float* out_act, int act_out, int B, int Cin, int Cout, int H, int W,
+                                      const ipdm_conv_ext_t* ext, void* stream) {
+  return wino1d_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, nullptr, ext, stream);
+}
+
+// statistics epilogue: partials per plane (0: the layer shape is not served) and the call that fills stats[B][Cout][partials][3]
+extern "C" int ipdm_conv2d_wino1d_stats_partials(int Cin, int Cout, int H, int W) {
+  if (!ipdm_conv2d_wino1d_supported(Cin, Cout, H, W)) return 0;
+  return ((W + 2 * Y_TX - 1) / (2 * Y_TX)) * ((H + Y_ROWS - 1) / Y_ROWS);
+}
+
+extern "C" int ipdm_conv2d_wino1d_stats_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
+                                            float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, float* stats,
+                                            const ipdm_conv_ext_t* ext, void* stream) {
+  IPDM_REQUIRE(stats != nullptr && out != nullptr);
+  return wino1d_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, stats, ext, stream);
 }

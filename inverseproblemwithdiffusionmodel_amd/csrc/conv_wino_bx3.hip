@@ -602,16 +602,6 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
 // pixels (a quad is then entirely inside or entirely outside the image, so the range check still pads), 25-27
 // wave-instructions per chunk and workgroup instead of 96 -- an LDS-DMA instruction costs ~100 issue cycles next to
 // MFMAs, whatever its width.
-// sum over the 32 lanes of a half-wave, the total in every lane: four DPP adds inside the 16-lane rows (quad swaps, then the
-// half-row and row mirrors) and one cross-row exchange -- a fixed order, and a fifth of the latency of five bpermutes
-__device__ __forceinline__ float half_wave_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
-  return v + __shfl_xor(v, 16, 64);
-}
-
 // STATS: the epilogue also reduces every (channel, tile group) of the workgroup's tile block to (count, mean, sum of squared
 // deviations) of the stored result and writes them to a.stats (own instantiation, same reason as POOL).
 // KSP: the K loop of a tile is dealt to a.ksplit workgroups (each a contiguous range of n_cc / ksplit chunks); every part

@@ -118,7 +118,8 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
         if (USE_WINOGRAD and ops.split_impl() and self.ndim == 2 and self.kernel_size == 3 and coef is None
                 and act == ops.ACT_NONE and out is None and ops.wino_bx3_pays(self.in_planes, self.out_planes, x.shape[2],
                                                                               x.shape[3], self.dilation)):
-            one_d = (not (want_stats and raw and ops.USE_STATS_EPILOGUE) and x.data_ptr() % 16 == 0
+            one_d = (x.data_ptr() % 16 == 0 and act_out in (ops.ACT_NONE, ops.ACT_ELU, ops.ACT_COPY)
+                     and (ops.WINO1D_STATS or not (want_stats and raw and ops.USE_STATS_EPILOGUE))
                      and ops.wino1d_pays(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation))
             return ops.conv2d_wino_bx3(x, self.packed_wino1d() if one_d else self.packed_wino_bx3(), bias, residual,
                                        act_out=act_out, raw=raw, dilation=self.dilation, want_stats=want_stats, in_amax=in_amax,

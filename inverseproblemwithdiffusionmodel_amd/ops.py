@@ -1192,7 +1192,8 @@ def conv_wino1d_weight(w):
     return PackedBx3(blob, Cout, Cin, 12, "hx2")
 
 
-WINO1D = os.environ.get("IPDM_WINO1D", "0") != "0"
+WINO1D = os.environ.get("IPDM_WINO1D", "1") != "0"          # 0: the 2-D Winograd kernel everywhere (A/B, fallback)
+WINO1D_STATS = os.environ.get("IPDM_WINO1D_STATS", "1") != "0"      # the launches with a statistics epilogue too (tuning)
 
 
 def wino1d_pays(Cin, Cout, H, W, dilation=1):
@@ -1275,8 +1276,9 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
         tag_amax(out_act, slot_a)
         return (out, out_act) if want_act else out
     part = None
-    if want_stats and raw and USE_STATS_EPILOGUE and x.data_ptr() % 16 == 0 and not one_d:
-        P = int(_lib.lib.ipdm_conv2d_wino_bx3_stats_partials(Cin, Cout, H, W, dilation, int(bool(pool2))))
+    if want_stats and raw and USE_STATS_EPILOGUE and x.data_ptr() % 16 == 0:
+        P = (int(_lib.lib.ipdm_conv2d_wino1d_stats_partials(Cin, Cout, H, W)) if one_d else
+             int(_lib.lib.ipdm_conv2d_wino_bx3_stats_partials(Cin, Cout, H, W, dilation, int(bool(pool2)))))
         if P > 0:
             part = torch.empty((B, Cout, P, 3), dtype=torch.float32, device=x.device)
     for b0 in range(0, B, nb):           # one launch unless the batch outgrows the kernel's 32-bit buffer offsets
@@ -1287,7 +1289,10 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
                 int(bool(pool2)))
         am = (ext_of(b0, b1),)
         if one_d:
-            call("ipdm_conv2d_wino1d_f32", *args[:-2], *am, _stream())
+            if part is not None:
+                call("ipdm_conv2d_wino1d_stats_f32", *args[:-2], _ptr(part[b0:b1]), *am, _stream())
+            else:
+                call("ipdm_conv2d_wino1d_f32", *args[:-2], *am, _stream())
             continue
         if part is not None:
             try:
@@ -1301,7 +1306,7 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
     if CONV_TRACE is not None:
         e1.record()
         CONV_TRACE.append(dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=dilation, wino=True, bx3=True, fmt=U.fmt, res=residual is not None,
-                               n_out=int(raw) + int(want_act), pool2=bool(pool2), wino1d=one_d, e0=e0, e1=e1))
+                               n_out=int(raw) + int(want_act), pool2=bool(pool2), wino1d=one_d, stats=part is not None, e0=e0, e1=e1))
     tag_amax(out, slot_o)
     tag_amax(out_act, slot_a)
     return (out, out_act) if want_act else out
