@@ -56,6 +56,9 @@ class Conv(ops.PackedWeightMixin, nn.Module):
         impl = ops.impl_unbounded()
         return self._cache.get(self.weight, "wino_" + impl, lambda w: ops.conv_wino_split_weight(w, impl))
 
+    def packed_wino1d(self):
+        return self._cache.get(self.weight, "wino1d", ops.conv_wino1d_weight)
+
     def forward(self, x, residual=None, bounded=False, bias_rows=None, out_scale=1.0, in_amax=None, feeds_conv=False):
         """bounded: x is act(GroupNorm(.)) (possibly FIR-resampled) -- |x| <= |gamma| sqrt(group size) + |beta|, inside the
         f16x2 family's static range; otherwise (raw skip / pyramid / input streams) the convolution runs with the dynamic
@@ -78,8 +81,10 @@ class Conv(ops.PackedWeightMixin, nn.Module):
             return ops.conv3x3_thin(x, self.weight.data, bias)         # first / last layer: streaming kernels
         if (ops.impl_unbounded() in ops.SPLIT_IMPLS and self.kernel_size == 3
                 and ops.wino_bx3_pays(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation)):
-            return ops.conv2d_wino_bx3(x, self.packed_wino(), bias, residual, dilation=self.dilation, in_amax=amax,
-                                       out_scale=out_scale, want_amax=produce)
+            one_d = (impl == "hx2" and x.data_ptr() % 16 == 0
+                     and ops.wino1d_pays(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation))
+            return ops.conv2d_wino_bx3(x, self.packed_wino1d() if one_d else self.packed_wino(), bias, residual,
+                                       dilation=self.dilation, in_amax=amax, out_scale=out_scale, want_amax=produce)
         return ops.conv2d(x, self.packed(), bias, residual=residual, dilation=self.dilation, in_amax=amax, out_scale=out_scale,
                           want_amax=produce)
 
