@@ -446,19 +446,20 @@ int ipdm_conv2d_wino_hx2_f32(const float* x, const void* U, const float* bias, c
                              int pool2, const ipdm_conv_ext_t* ext, void* stream);
 /* 1-D Winograd form of the same 3x3 convolution on f16x2 operands (conv_wino1d.hip): F(2,3) along x, the filter's three rows as
  * K -- 4 positions instead of 16, 128 output channels per workgroup, 12 instead of 16 weight values per (co, ci) and 1.5x the
- * matrix instructions.  Same arguments as ipdm_conv2d_wino_hx2_f32 without dilation / pool2 (undilated, unpooled launches;
- * Cin % 32 == 0, Cout % 128 == 0, W % 4 == 0 and >= 32, H even and >= 8: ipdm_conv2d_wino1d_supported); its own weight blob. */
+ * matrix instructions.  Same arguments as ipdm_conv2d_wino_hx2_f32 without the dilation (undilated launches; Cin % 32 == 0,
+ * Cout % 128 == 0, W % 4 == 0 and >= 32, H even and >= 8: ipdm_conv2d_wino1d_supported; activated copy: ELU or
+ * IPDM_ACT_COPY); its own weight blob. */
 int64_t ipdm_conv_wino1d_weight_bytes(int Cout, int Cin);
 int ipdm_conv_wino1d_pack_weight(const float* w /* [Cout][Cin][3][3] */, void* U, int Cout, int Cin, void* stream);
 int ipdm_conv2d_wino1d_supported(int Cin, int Cout, int H, int W);
 int ipdm_conv2d_wino1d_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
-                           float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, const ipdm_conv_ext_t* ext,
-                           void* stream);
+                           float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int pool2,
+                           const ipdm_conv_ext_t* ext, void* stream);
 /* ... with the statistics epilogue (as ipdm_conv2d_wino_hx2_stats_f32): stats[B][Cout][P][3] = (count, mean, sum of squared
  * deviations) of `out` per 8 x 32 pixel block, P = ipdm_conv2d_wino1d_stats_partials (0: not served) */
 int ipdm_conv2d_wino1d_stats_partials(int Cin, int Cout, int H, int W);
 int ipdm_conv2d_wino1d_stats_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
-                                 float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, float* stats,
+                                 float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int pool2, float* stats,
                                  const ipdm_conv_ext_t* ext, void* stream);
 int ipdm_conv2d_wino_hx2_splitk_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
                                     float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,

@@ -93,7 +93,9 @@ __global__ __launch_bounds__(256) void wino1d_weight_kernel(const float* __restr
 // OUTS 1: out, 2: out_act, 3: both (the launcher picks; no branch per store).  STATS: per (image, channel, pixel block) the stored `out`
 // values are reduced to (count, mean, sum of squared deviations) partials [B][Cout][tiles_y * tiles_x][3] for the InstanceNorm++
 // that follows (deterministic: fixed butterflies inside a half-wave, the four rounds of a channel tile accumulated in registers)
-template <int OUTS, bool STATS = false>
+// POOL: the ConvMeanPool epilogue -- a column block's two rows are the two rows of the 2x2 pooling windows: the lower row's values come
+// by one cross-row exchange, the upper row's lanes store the mean [B][Cout][H/2][W/2] (residual and statistics at that size)
+template <int OUTS, bool STATS = false, bool POOL = false>
 __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_tiles) {
   extern __shared__ __align__(16) float lds[];
   unsigned* const ldsw = reinterpret_cast<unsigned*>(lds);
@@ -367,11 +369,13 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
     const int ecol = tid & 31, ecg = tid >> 5;                  // this thread: column, channels k*16 + ecg of the round's 64
     const int co0 = cur_g.cob * Y_CO;
     const float* const scale_p = reinterpret_cast<const float*>(wq + 12 * pos_stride);
-    const size_t tile_base = (((size_t)cur_g.b * a.Cout + co0) * HW + (size_t)cur_g.y0 * a.W + cur_g.x0) * 4;
-    unsigned eoff4 = 4u * (unsigned)(ecg * HW + (ecol >> 4) * a.W + 2 * (ecol & 15));
+    const int oHW = POOL ? HW >> 2 : HW, oW = POOL ? a.W >> 1 : a.W;     // the written tensor's plane / row
+    const size_t tile_base = (((size_t)cur_g.b * a.Cout + co0) * oHW + (size_t)(POOL ? cur_g.y0 >> 1 : cur_g.y0) * oW +
+                              (POOL ? cur_g.x0 >> 1 : cur_g.x0)) * 4;
+    unsigned eoff4 = 4u * (unsigned)(ecg * oHW + (POOL ? (ecol & 15) : (ecol >> 4) * oW + 2 * (ecol & 15)));
     asm volatile("" : "+v"(eoff4));
     auto boff = [&](int c, int nb, int k) -> unsigned {
-      return 4u * (unsigned)((((k >> 1) * 2 + c) * 32 + (k & 1) * 16) * HW + (2 * nb) * a.W) + eoff4;
+      return 4u * (unsigned)((((k >> 1) * 2 + c) * 32 + (k & 1) * 16) * oHW + (POOL ? nb : 2 * nb) * oW) + eoff4;
     };
     auto in_range = [&](int nb) { return cur_g.y0 + 2 * nb + (ecol >> 4) < a.H && cur_g.x0 + 2 * (ecol & 15) < a.W; };
     const bool has_res = a.residual != nullptr, has_bias = a.bias != nullptr;
@@ -381,16 +385,18 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
     const char* const res_b = reinterpret_cast<const char*>(res_p) + (has_res ? tile_base : 0);
     [[maybe_unused]] char* const out_b = reinterpret_cast<char*>(a.out) + tile_base;
     [[maybe_unused]] char* const act_b = reinterpret_cast<char*>(a.out_act) + tile_base;
-    float2 resv[2][4];
+    constexpr int NV = POOL ? 1 : 2;                            // stored values per (thread, channel)
+    typedef float vecv __attribute__((ext_vector_type(NV)));
+    vecv resv[2][4];
     // (unconditional loads -- an absent operand or an out-of-range column reads the weight blob -- so that hipcc can count them)
     auto prefetch = [&](auto rc) {
       constexpr int rnd = decltype(rc)::value;
       constexpr int c = rnd >> 2, nb = rnd & 3, bf = rnd & 1;
-      const bool res_ok = has_res && in_range(nb);
+      const bool res_ok = has_res && in_range(nb) && (!POOL || (ecol >> 4) == 0);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const unsigned ob = res_ok ? boff(c, nb, k) : 0u;
-        resv[bf][k] = *reinterpret_cast<const float2*>(res_b + ob);
+        resv[bf][k] = *reinterpret_cast<const vecv*>(res_b + ob);
       }
     };
     if (cur_g.b != pend_b) {
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
       __syncthreads();
       W1D_TE(1);
       if constexpr (rnd < 7) prefetch(std::integral_constant<int, rnd + 1>{});
-      const bool inr = in_range(nb);
+      const bool inr = in_range(nb) && (!POOL || (ecol >> 4) == 0);   // this thread stores (POOL: the windows' upper rows do)
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         float m[2][4], sc[2], bi[2];
@@ -442,57 +448,63 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
 #pragma unroll
           for (int x = 0; x < 4; ++x) m[kk][x] = mw[(x * 64 + k * 16 + ecg) * 32 + ecol];
         }
-        float2 ov[2], ev[2];
+        vecv ov[2], ev[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const int k = half * 2 + kk;
-          float y0v = __builtin_fmaf(m[kk][0] + m[kk][1] + m[kk][2], sc[kk], bi[kk]);
-          float y1v = __builtin_fmaf(m[kk][1] - m[kk][2] - m[kk][3], sc[kk], bi[kk]);
-          float r0v = y0v, r1v = y1v;
-          y0v += has_res ? resv[bf][k].x : 0.f;
-          y1v += has_res ? resv[bf][k].y : 0.f;
-          r0v = a.res_second ? r0v : y0v;
-          r1v = a.res_second ? r1v : y1v;
-          y0v *= a.out_scale;
-          y1v *= a.out_scale;
-          r0v *= a.out_scale;
-          r1v *= a.out_scale;
-          ov[kk] = make_float2(r0v, r1v);
-          if constexpr (STATS) {
-            if constexpr (nb == 0) {
-              // the shift K is taken FROM the data (the half-wave's first value of the channel tile's first round), so that the
-              // subtraction below cancels nothing the spread of the data does not
-              const float k0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r0v), 0));
-              const float k1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r0v), 32));
-              st_k[k] = h ? k1 : k0;
-              st_s1[k] = st_s2[k] = 0.f;
-            }
-            const float d0 = inr ? r0v - st_k[k] : 0.f, d1 = inr ? r1v - st_k[k] : 0.f;
-            st_s1[k] += d0 + d1;
-            st_s2[k] = __builtin_fmaf(d0, d0, __builtin_fmaf(d1, d1, st_s2[k]));
+          float yv[2];
+          yv[0] = __builtin_fmaf(m[kk][0] + m[kk][1] + m[kk][2], sc[kk], bi[kk]);
+          yv[1] = __builtin_fmaf(m[kk][1] - m[kk][2] - m[kk][3], sc[kk], bi[kk]);
+          if constexpr (POOL) {
+            // (y[::2,::2] + y[1::2,::2] + y[::2,1::2] + y[1::2,1::2]) / 4 in the reference's order (layers.py:291-313)
+            const float p0 = __shfl_xor(yv[0], 16, 64), p1 = __shfl_xor(yv[1], 16, 64);
+            yv[0] = (((yv[0] + p0) + yv[1]) + p1) * 0.25f;
           }
-          if constexpr (W_OUT) amx_o = fmaxf(amx_o, inr ? fmaxf(fabsf(r0v), fabsf(r1v)) : 0.f);
-          if constexpr (W_ACT) {
-            const float e0 = elu ? fast_elu(y0v) : y0v, e1 = elu ? fast_elu(y1v) : y1v;
-            ev[kk] = make_float2(e0, e1);
-            amx_a = fmaxf(amx_a, inr ? fmaxf(fabsf(e0), fabsf(e1)) : 0.f);
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            float y = yv[v], rv = yv[v];
+            y += has_res ? resv[bf][k][v] : 0.f;
+            rv = a.res_second ? rv : y;
+            y *= a.out_scale;
+            rv *= a.out_scale;
+            ov[kk][v] = rv;
+            if constexpr (STATS) {
+              if constexpr (nb == 0) {
+                if (v == 0) {
+                  // the shift K is taken FROM the data (the half-wave's first value of the channel tile's first round), so that
+                  // the subtraction below cancels nothing the spread of the data does not
+                  const float k0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv), 0));
+                  const float k1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv), 32));
+                  st_k[k] = h ? k1 : k0;
+                  st_s1[k] = st_s2[k] = 0.f;
+                }
+              }
+              const float d = inr ? rv - st_k[k] : 0.f;
+              st_s1[k] += d;
+              st_s2[k] = __builtin_fmaf(d, d, st_s2[k]);
+            }
+            if constexpr (W_OUT) amx_o = fmaxf(amx_o, inr ? fabsf(rv) : 0.f);
+            if constexpr (W_ACT) {
+              const float e = elu ? fast_elu(y) : y;
+              ev[kk][v] = e;
+              amx_a = fmaxf(amx_a, inr ? fabsf(e) : 0.f);
+            }
           }
         }
         if (inr) {
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) {
             const unsigned ob = boff(c, nb, half * 2 + kk);
-            typedef float ntf2 __attribute__((ext_vector_type(2)));
-            if constexpr (W_OUT) __builtin_nontemporal_store(ntf2{ov[kk].x, ov[kk].y}, reinterpret_cast<ntf2*>(out_b + ob));
-            if constexpr (W_ACT) *reinterpret_cast<float2*>(act_b + ob) = ev[kk];
+            if constexpr (W_OUT) __builtin_nontemporal_store(ov[kk], reinterpret_cast<vecv*>(out_b + ob));
+            if constexpr (W_ACT) *reinterpret_cast<vecv*>(act_b + ob) = ev[kk];
           }
         }
       }
       if constexpr (STATS) {
         const unsigned long long bal = __ballot(inr);
         if constexpr (nb == 0) st_c0 = st_c1 = 0;
-        st_c0 += 2 * __popcll(bal & 0xffffffffull);
-        st_c1 += 2 * __popcll(bal >> 32);
+        st_c0 += NV * __popcll(bal & 0xffffffffull);
+        st_c1 += NV * __popcll(bal >> 32);
         if constexpr (nb == 3) {
           const float cnt = (float)(h ? st_c1 : st_c0);
           const int tb = (cur_g.y0 / Y_ROWS) * a.tiles_x + cur_g.x0 / (2 * Y_TX);
@@ -546,7 +558,6 @@ bool wino1d_ok(const ConvArgs& a) {
   if (!(a.D == 1 && a.dil == 1 && a.Cin % (2 * Y_KC) == 0 && a.Cout % Y_CO == 0 && !a.coef && a.act == IPDM_ACT_NONE)) return false;
   if (a.out_act && a.act_out != IPDM_ACT_ELU && a.act_out != IPDM_ACT_COPY) return false;    // the epilogue's branch-free activations
   if ((size_t)a.B * a.Cin * a.H * a.W * 4 >= 0x3fffffffull) return false;
-  if (a.pool2) return false;
   if (a.stats && !a.out) return false;
   return a.H % 2 == 0 && a.W % 4 == 0 && a.H >= 8 && a.W >= 32 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
 }
@@ -565,9 +576,11 @@ int conv_wino1d_launch(ConvArgs a, hipStream_t s) {
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    const void* kernels[] = {reinterpret_cast<const void*>(conv_wino1d_kernel<1>), reinterpret_cast<const void*>(conv_wino1d_kernel<2>),
-                             reinterpret_cast<const void*>(conv_wino1d_kernel<3>), reinterpret_cast<const void*>(conv_wino1d_kernel<1, true>),
-                             reinterpret_cast<const void*>(conv_wino1d_kernel<3, true>)};
+    const void* kernels[] = {reinterpret_cast<const void*>(conv_wino1d_kernel<1, false, false>), reinterpret_cast<const void*>(conv_wino1d_kernel<2, false, false>),
+                             reinterpret_cast<const void*>(conv_wino1d_kernel<3, false, false>), reinterpret_cast<const void*>(conv_wino1d_kernel<1, true, false>),
+                             reinterpret_cast<const void*>(conv_wino1d_kernel<3, true, false>), reinterpret_cast<const void*>(conv_wino1d_kernel<1, false, true>),
+                             reinterpret_cast<const void*>(conv_wino1d_kernel<2, false, true>), reinterpret_cast<const void*>(conv_wino1d_kernel<3, false, true>),
+                             reinterpret_cast<const void*>(conv_wino1d_kernel<1, true, true>), reinterpret_cast<const void*>(conv_wino1d_kernel<3, true, true>)};
     for (const void* k : kernels) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Y_LDS_BYTES);
       if (e != hipSuccess) return (int)e;
@@ -579,16 +592,19 @@ int conv_wino1d_launch(ConvArgs a, hipStream_t s) {
     cus = 256;
   const int per_xcd = (int)((nblk + 7) / 8);
   const int S = per_xcd < cus / 8 ? per_xcd : cus / 8;
-  if (a.stats && a.out_act)
-    hipLaunchKernelGGL((conv_wino1d_kernel<3, true>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
-  else if (a.stats)
-    hipLaunchKernelGGL((conv_wino1d_kernel<1, true>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
-  else if (a.out && a.out_act)
-    hipLaunchKernelGGL((conv_wino1d_kernel<3>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
-  else if (a.out)
-    hipLaunchKernelGGL((conv_wino1d_kernel<1>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
-  else
-    hipLaunchKernelGGL((conv_wino1d_kernel<2>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
+  const int outs = (a.out ? 1 : 0) | (a.out_act ? 2 : 0);
+#define W1D_LAUNCH(O, S_, P_) hipLaunchKernelGGL((conv_wino1d_kernel<O, S_, P_>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk)
+  if (a.pool2) {
+    if (a.stats) { if (outs == 3) W1D_LAUNCH(3, true, true); else W1D_LAUNCH(1, true, true); }
+    else if (outs == 3) W1D_LAUNCH(3, false, true);
+    else if (outs == 1) W1D_LAUNCH(1, false, true);
+    else W1D_LAUNCH(2, false, true);
+  } else if (a.stats) {
+    if (outs == 3) W1D_LAUNCH(3, true, false); else W1D_LAUNCH(1, true, false);
+  } else if (outs == 3) W1D_LAUNCH(3, false, false);
+  else if (outs == 1) W1D_LAUNCH(1, false, false);
+  else W1D_LAUNCH(2, false, false);
+#undef W1D_LAUNCH
   return ipdm_launch_status();
 }
 
@@ -623,7 +639,8 @@ extern "C" int ipdm_conv2d_wino1d_supported(int Cin, int Cout, int H, int W) {
 }
 
 static int wino1d_entry(const float* x, const void* U, const float* bias, const float* residual, float* out, float* out_act,
-                        int act_out, int B, int Cin, int Cout, int H, int W, float* stats, const ipdm_conv_ext_t* ext, void* stream) {
+                        int act_out, int B, int Cin, int Cout, int H, int W, int pool2, float* stats, const ipdm_conv_ext_t* ext,
+                        void* stream) {
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && U && (out || out_act) && x != out && x != out_act);
@@ -633,15 +650,16 @@ static int wino1d_entry(const float* x, const void* U, const float* bias, const 
   a.D = 1; a.kd = 1; a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
   a.hx = 1;
   a.stats = stats;
+  a.pool2 = pool2 ? 1 : 0;
   conv_apply_ext(a, ext, 1);
   if (!wino1d_ok(a)) return IPDM_EUNSUPPORTED;
   return conv_wino1d_launch(a, ipdm_stream(stream));
 }
 
 extern "C" int ipdm_conv2d_wino1d_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
-                                      float* out_act, int act_out, int B, int Cin, int Cout, int H, int W,
+                                      float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int pool2,
                                       const ipdm_conv_ext_t* ext, void* stream) {
-  return wino1d_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, nullptr, ext, stream);
+  return wino1d_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, pool2, nullptr, ext, stream);
 }
 
 // statistics epilogue: partials per plane (0: the layer shape is not served) and the call that fills stats[B][Cout][partials][3]
@@ -651,8 +669,8 @@ extern "C" int ipdm_conv2d_wino1d_stats_partials(int Cin, int Cout, int H, int W
 }
 
 extern "C" int ipdm_conv2d_wino1d_stats_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
-                                            float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, float* stats,
-                                            const ipdm_conv_ext_t* ext, void* stream) {
+                                            float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int pool2,
+                                            float* stats, const ipdm_conv_ext_t* ext, void* stream) {
   IPDM_REQUIRE(stats != nullptr && out != nullptr);
-  return wino1d_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, stats, ext, stream);
+  return wino1d_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, pool2, stats, ext, stream);
 }

@@ -174,8 +174,11 @@ class ConvMeanPool(nn.Module):
                 and inputs.shape[2] % 2 == 0 and inputs.shape[3] % 2 == 0
                 and ops.wino_bx3_pays(c.in_planes, c.out_planes, inputs.shape[2], inputs.shape[3], 1)):
             return None
+        one_d = (inputs.data_ptr() % 16 == 0 and act_out in (ops.ACT_NONE, ops.ACT_ELU, ops.ACT_COPY) and ops.WINO1D_STATS
+                 and ops.wino1d_pays(c.in_planes, c.out_planes, inputs.shape[2], inputs.shape[3], 1))
         try:
-            return ops.conv2d_wino_bx3(inputs, c.packed_wino_bx3(), None if c.bias is None else c.bias.data, residual,
+            return ops.conv2d_wino_bx3(inputs, c.packed_wino1d() if one_d else c.packed_wino_bx3(),
+                                       None if c.bias is None else c.bias.data, residual,
                                        act_out=act_out, pool2=True, want_stats=True,     # a block's result: normalised next
                                        in_amax=ops.in_amax_for(inputs), want_amax=ops.dynamic_range() and feeds_conv)
         except _lib.IpdmUnsupported:

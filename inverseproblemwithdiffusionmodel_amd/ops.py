@@ -1244,8 +1244,8 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
     one_d = U.kk == 12                   # conv_wino1d_weight: 1-D Winograd along x (conv_wino1d.hip), plain epilogues only
     if U.kk not in (12, 16) or U.Cin != Cin:
         raise ValueError("conv2d_wino_bx3: weight blob does not match the input")
-    if one_d and (pool2 or dilation != 1 or U.fmt != "hx2"):
-        raise ValueError("conv2d_wino_bx3: the 1-D Winograd blob serves undilated, unpooled f16x2 launches only")
+    if one_d and (dilation != 1 or U.fmt != "hx2"):
+        raise ValueError("conv2d_wino_bx3: the 1-D Winograd blob serves undilated f16x2 launches only")
     if res_second and (residual is None or act_out == ACT_NONE or not raw):
         raise ValueError("conv2d_wino_bx3: res_second needs a residual and both outputs (act_out, e.g. ACT_COPY; raw=True)")
     Cout = U.Cout
@@ -1289,10 +1289,11 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
                 int(bool(pool2)))
         am = (ext_of(b0, b1),)
         if one_d:
+            a1 = args[:-2] + args[-1:]                  # (no dilation argument)
             if part is not None:
-                call("ipdm_conv2d_wino1d_stats_f32", *args[:-2], _ptr(part[b0:b1]), *am, _stream())
+                call("ipdm_conv2d_wino1d_stats_f32", *a1, _ptr(part[b0:b1]), *am, _stream())
             else:
-                call("ipdm_conv2d_wino1d_f32", *args[:-2], *am, _stream())
+                call("ipdm_conv2d_wino1d_f32", *a1, *am, _stream())
             continue
         if part is not None:
             try:

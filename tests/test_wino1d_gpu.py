@@ -91,9 +91,40 @@ def test_wino1d_unsupported_shapes_and_activations(ops):
     with pytest.raises(ops._lib.IpdmUnsupported):
         ops.conv2d_wino_bx3(x, U, b, act_out=ops.ACT_SWISH)               # the epilogue's activations: ELU and copy
     with pytest.raises(ValueError):
-        ops.conv2d_wino_bx3(x, U, b, pool2=True)
-    with pytest.raises(ValueError):
         ops.conv2d_wino_bx3(x, U, b, dilation=2)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,res", [(2, 64, 128, 64, 32, True), (1, 32, 128, 34, 44, False), (2, 128, 256, 16, 64, True)])
+def test_wino1d_pooled_epilogue(ops, B, Cin, Cout, H, W, res):
+    """ConvMeanPool in one launch (layers.py:291-313): 2x2 mean of the convolution in the reference's summation order, pooled-size
+    residual, activated copy, maxima and statistics of the pooled result; ragged blocks (H = 34, W = 44)"""
+    gen = torch.Generator().manual_seed(43)
+    x = torch.randn(B, Cin, H, W, generator=gen).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.1).cuda()
+    b = torch.randn(Cout, generator=gen).cuda()
+    r = (torch.randn(B, Cout, H // 2, W // 2, generator=gen) * 2 + 3).cuda() if res else None
+    U = ops.conv_wino1d_weight(w)
+    with ops.amax_scope():
+        y, ya = ops.conv2d_wino_bx3(x, U, b, r, act_out=ops.ACT_ELU, pool2=True, want_stats=True, want_amax=True)
+        conv = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        ref = (conv[..., ::2, ::2] + conv[..., 1::2, ::2] + conv[..., ::2, 1::2] + conv[..., 1::2, 1::2]) / 4
+        if res:
+            ref = ref + r.double()
+        assert tuple(y.shape) == (B, Cout, H // 2, W // 2)
+        assert (y.double() - ref).abs().max() <= 1e-6 * ref.abs().max()
+        assert (ya.double() - F.elu(ref)).abs().max() <= 1e-6 * ref.abs().max()
+        assert torch.equal(ops.amax_value(ops.amax_of(y)), y.abs().amax(dim=(1, 2, 3)))
+        assert torch.equal(ops.amax_value(ops.amax_of(ya)), ya.abs().amax(dim=(1, 2, 3)))
+    part, _ = y._ipdm_partials
+    assert float(part[..., 0].sum(dim=2).min()) == (H // 2) * (W // 2) == float(part[..., 0].sum(dim=2).max())
+    ones = torch.ones(Cout).cuda()
+    c_part = ops.instnorm_plus_coef(y, ones, ones, None)
+    c_full = ops.instnorm_plus_coef(y, ones, ones, None)                   # partials consumed: a pass over the tensor
+    assert (c_part - c_full).abs().max() <= 2e-5 * c_full.abs().max()
+    y1 = ops.conv2d_wino_bx3(x, U, b, r, pool2=True)                       # plain pooled launch: the same bits
+    assert torch.equal(y1, y)
+    y2 = ops.conv2d_wino_bx3(x, ops.conv_wino_hx2_weight(w), b, r, pool2=True)      # the 2-D kernel's pooled epilogue
+    assert (y1 - y2).abs().max() <= 1e-6 * y2.abs().max()
 
 
 @pytest.mark.parametrize("scale", [1e-5, 1.0, 3e4, 1e8])
