@@ -452,15 +452,17 @@ int ipdm_conv2d_wino_hx2_f32(const float* x, const void* U, const float* bias, c
 int64_t ipdm_conv_wino1d_weight_bytes(int Cout, int Cin);
 int ipdm_conv_wino1d_pack_weight(const float* w /* [Cout][Cin][3][3] */, void* U, int Cout, int Cin, void* stream);
 int ipdm_conv2d_wino1d_supported(int Cin, int Cout, int H, int W);
-int ipdm_conv2d_wino1d_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
-                           float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int pool2,
-                           const ipdm_conv_ext_t* ext, void* stream);
+/* coef != NULL: the input is act(InstanceNorm++(x)) -- coef [B][Cin][3] from ipdm_instnorm_plus_coef_f32, act = IPDM_ACT_ELU --
+ * applied inside the kernel (as ipdm_conv2d_hx2_f32's fused input); ext->in_amax is then the coefficient kernel's bound. */
+int ipdm_conv2d_wino1d_f32(const float* x, const void* U, const float* bias, const float* coef, int act,
+                           const float* residual, float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H,
+                           int W, int pool2, const ipdm_conv_ext_t* ext, void* stream);
 /* ... with the statistics epilogue (as ipdm_conv2d_wino_hx2_stats_f32): stats[B][Cout][P][3] = (count, mean, sum of squared
  * deviations) of `out` per 8 x 32 pixel block, P = ipdm_conv2d_wino1d_stats_partials (0: not served) */
 int ipdm_conv2d_wino1d_stats_partials(int Cin, int Cout, int H, int W);
-int ipdm_conv2d_wino1d_stats_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
-                                 float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int pool2, float* stats,
-                                 const ipdm_conv_ext_t* ext, void* stream);
+int ipdm_conv2d_wino1d_stats_f32(const float* x, const void* U, const float* bias, const float* coef, int act,
+                                 const float* residual, float* out, float* out_act, int act_out, int B, int Cin, int Cout,
+                                 int H, int W, int pool2, float* stats, const ipdm_conv_ext_t* ext, void* stream);
 int ipdm_conv2d_wino_hx2_splitk_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
                                     float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int dilation,
                                     int ksplit, float* work, const ipdm_conv_ext_t* ext, void* stream);

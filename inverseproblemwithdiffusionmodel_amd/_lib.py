@@ -104,9 +104,9 @@ SIGNATURES = {
     "ipdm_conv_wino1d_weight_bytes": [c_int, c_int],
     "ipdm_conv_wino1d_pack_weight": [P, P, c_int, c_int, P],
     "ipdm_conv2d_wino1d_supported": [c_int, c_int, c_int, c_int],
-    "ipdm_conv2d_wino1d_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
+    "ipdm_conv2d_wino1d_f32": [P, P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "ipdm_conv2d_wino1d_stats_partials": [c_int, c_int, c_int, c_int],
-    "ipdm_conv2d_wino1d_stats_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P],
+    "ipdm_conv2d_wino1d_stats_f32": [P, P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P],
     "ipdm_conv_wino_hx2_pack_weight": [P, P, c_int, c_int, P],
     "ipdm_conv2d_wino_hx2_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "ipdm_conv2d_wino_hx2_splitk_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P],

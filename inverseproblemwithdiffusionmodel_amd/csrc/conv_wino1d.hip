@@ -95,7 +95,10 @@ __global__ __launch_bounds__(256) void wino1d_weight_kernel(const float* __restr
 // that follows (deterministic: fixed butterflies inside a half-wave, the four rounds of a channel tile accumulated in registers)
 // POOL: the ConvMeanPool epilogue -- a column block's two rows are the two rows of the 2x2 pooling windows: the lower row's values come
 // by one cross-row exchange, the upper row's lanes store the mean [B][Cout][H/2][W/2] (residual and statistics at that size)
-template <int OUTS, bool STATS = false, bool POOL = false>
+// FIN: the input is act(InstanceNorm++(x)) of a raw tensor x (a.coef [B][Cin][3]: (x - mu) * scale + shift, then ELU): applied to the raw
+// rows on their way through the producer's registers -- every raw value once per row item, the padding kept at zero -- instead of an
+// affine + activation pass that writes the normalised tensor and reads it back (8 bytes of HBM per element)
+template <int OUTS, bool STATS = false, bool POOL = false, bool FIN = false>
 __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_tiles) {
   extern __shared__ __align__(16) float lds[];
   unsigned* const ldsw = reinterpret_cast<unsigned*>(lds);
@@ -201,9 +204,37 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
   };
   // word offset of this thread's stores inside a staged row: channel pair cp = wave -> k half cp >> 2, q = cp & 3
   const int v_st = ((wave & 3) >> 1) * 64 + (wave >> 2) * 32 + (wave & 1) * 16 + pt;
+  // FIN: coefficients of the wave's two channels and the in-image predicates of the chunk being staged
+  [[maybe_unused]] float fin_mu[2] = {0.f, 0.f}, fin_sc[2] = {1.f, 1.f}, fin_sh[2] = {0.f, 0.f};
+  [[maybe_unused]] int fin_row = 0;                             // image row of this thread's first item
+  [[maybe_unused]] bool fin_pair = true, fin_edge = true;
+  [[maybe_unused]] auto set_fin = [&](int b, int chunk, int y0, int x0) {
+    if constexpr (FIN) {
+      const float* cf = a.coef + ((size_t)b * a.Cin + chunk * Y_KC + 2 * wave) * 3;
+#pragma unroll
+      for (int cl = 0; cl < 2; ++cl) {
+        fin_mu[cl] = cf[cl * 3];
+        fin_sc[cl] = cf[cl * 3 + 1];
+        fin_sh[cl] = cf[cl * 3 + 2];
+      }
+      fin_row = y0 - 1 + rsub;
+      fin_pair = x0 + 2 * pt < a.W;
+      fin_edge = pfirst ? x0 > 0 : x0 + 2 * Y_TX < a.W;
+    }
+  };
   auto xform_item = [&](auto itc, float (&va)[4], float (&vb)[4]) {
     constexpr int it = decltype(itc)::value;
-    const Raw& r = raw[it];
+    Raw r = raw[it];
+    if constexpr (FIN) {
+      const bool rok = (unsigned)(fin_row + 4 * it) < (unsigned)a.H;
+      const bool pok = rok && fin_pair, eok = rok && fin_edge;
+      auto fin = [&](float v, int cl, bool ok) {
+        const float t = fast_elu((v - fin_mu[cl]) * fin_sc[cl] + fin_sh[cl]);
+        return ok ? t : 0.f;                                      // the padding stays zero
+      };
+      r.qa.x = fin(r.qa.x, 0, pok); r.qa.y = fin(r.qa.y, 0, pok); r.ea = fin(r.ea, 0, eok);
+      r.qb.x = fin(r.qb.x, 1, pok); r.qb.y = fin(r.qb.y, 1, pok); r.eb = fin(r.eb, 1, eok);
+    }
     const float la = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r.qa.y), 0x111, 0xf, 0xf, true));
     const float ra = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r.qa.x), 0x101, 0xf, 0xf, true));
     const float lb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r.qb.y), 0x111, 0xf, 0xf, true));
@@ -274,6 +305,7 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
   issue_dma(0);
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
+  set_fin(cur_g.b, 0, cur_g.y0, cur_g.x0);
   stage_all(ldsw);
   __syncthreads();
   issue_dma(1);
@@ -309,6 +341,10 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
         if (a_next && next_g.b != cur_g.b) {
           [[maybe_unused]] float unused_out;
           hx_scales_of(next_g.b, hx_in, unused_out);
+        }
+        if constexpr (FIN) {
+          if (a_next) set_fin(next_g.b, 0, next_g.y0, next_g.x0);
+          else set_fin(cur_g.b, ch + 1, cur_g.y0, cur_g.x0);
         }
         uint4 bsh[2][2];
         // the wave's DMA of chunk ch+1 (issued a chunk ago) has landed: three fragment groups are younger, two of them still wanted
@@ -555,7 +591,8 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
 }  // namespace
 
 bool wino1d_ok(const ConvArgs& a) {
-  if (!(a.D == 1 && a.dil == 1 && a.Cin % (2 * Y_KC) == 0 && a.Cout % Y_CO == 0 && !a.coef && a.act == IPDM_ACT_NONE)) return false;
+  if (!(a.D == 1 && a.dil == 1 && a.Cin % (2 * Y_KC) == 0 && a.Cout % Y_CO == 0)) return false;
+  if (a.coef ? a.act != IPDM_ACT_ELU : a.act != IPDM_ACT_NONE) return false;              // fused input: InstanceNorm++ + ELU only
   if (a.out_act && a.act_out != IPDM_ACT_ELU && a.act_out != IPDM_ACT_COPY) return false;    // the epilogue's branch-free activations
   if ((size_t)a.B * a.Cin * a.H * a.W * 4 >= 0x3fffffffull) return false;
   if (a.stats && !a.out) return false;
@@ -576,11 +613,10 @@ int conv_wino1d_launch(ConvArgs a, hipStream_t s) {
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    const void* kernels[] = {reinterpret_cast<const void*>(conv_wino1d_kernel<1, false, false>), reinterpret_cast<const void*>(conv_wino1d_kernel<2, false, false>),
-                             reinterpret_cast<const void*>(conv_wino1d_kernel<3, false, false>), reinterpret_cast<const void*>(conv_wino1d_kernel<1, true, false>),
-                             reinterpret_cast<const void*>(conv_wino1d_kernel<3, true, false>), reinterpret_cast<const void*>(conv_wino1d_kernel<1, false, true>),
-                             reinterpret_cast<const void*>(conv_wino1d_kernel<2, false, true>), reinterpret_cast<const void*>(conv_wino1d_kernel<3, false, true>),
-                             reinterpret_cast<const void*>(conv_wino1d_kernel<1, true, true>), reinterpret_cast<const void*>(conv_wino1d_kernel<3, true, true>)};
+#define W1D_K(O, S_, P_) reinterpret_cast<const void*>(conv_wino1d_kernel<O, S_, P_, false>), reinterpret_cast<const void*>(conv_wino1d_kernel<O, S_, P_, true>)
+    const void* kernels[] = {W1D_K(1, false, false), W1D_K(2, false, false), W1D_K(3, false, false), W1D_K(1, true, false), W1D_K(3, true, false),
+                             W1D_K(1, false, true),  W1D_K(2, false, true),  W1D_K(3, false, true),  W1D_K(1, true, true),  W1D_K(3, true, true)};
+#undef W1D_K
     for (const void* k : kernels) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Y_LDS_BYTES);
       if (e != hipSuccess) return (int)e;
@@ -593,7 +629,11 @@ int conv_wino1d_launch(ConvArgs a, hipStream_t s) {
   const int per_xcd = (int)((nblk + 7) / 8);
   const int S = per_xcd < cus / 8 ? per_xcd : cus / 8;
   const int outs = (a.out ? 1 : 0) | (a.out_act ? 2 : 0);
-#define W1D_LAUNCH(O, S_, P_) hipLaunchKernelGGL((conv_wino1d_kernel<O, S_, P_>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk)
+#define W1D_LAUNCH(O, S_, P_)                                                                                                    \
+  do {                                                                                                                           \
+    if (a.coef) hipLaunchKernelGGL((conv_wino1d_kernel<O, S_, P_, true>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk); \
+    else hipLaunchKernelGGL((conv_wino1d_kernel<O, S_, P_, false>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);      \
+  } while (0)
   if (a.pool2) {
     if (a.stats) { if (outs == 3) W1D_LAUNCH(3, true, true); else W1D_LAUNCH(1, true, true); }
     else if (outs == 3) W1D_LAUNCH(3, false, true);
@@ -638,15 +678,15 @@ extern "C" int ipdm_conv2d_wino1d_supported(int Cin, int Cout, int H, int W) {
   return wino1d_ok(a) ? 1 : 0;
 }
 
-static int wino1d_entry(const float* x, const void* U, const float* bias, const float* residual, float* out, float* out_act,
-                        int act_out, int B, int Cin, int Cout, int H, int W, int pool2, float* stats, const ipdm_conv_ext_t* ext,
+static int wino1d_entry(const float* x, const void* U, const float* bias, const float* coef, int act, const float* residual,
+                        float* out, float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int pool2, float* stats, const ipdm_conv_ext_t* ext,
                         void* stream) {
   IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0);
   if (B == 0) return IPDM_OK;
   IPDM_REQUIRE(x && U && (out || out_act) && x != out && x != out_act);
   ConvArgs a;
-  a.x = x; a.wt = (const float*)U; a.bias = bias; a.coef = nullptr; a.residual = residual; a.out = out; a.out_act = out_act;
-  a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = 1; a.act = IPDM_ACT_NONE;
+  a.x = x; a.wt = (const float*)U; a.bias = bias; a.coef = coef; a.residual = residual; a.out = out; a.out_act = out_act;
+  a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = 1; a.act = coef ? act : IPDM_ACT_NONE;
   a.D = 1; a.kd = 1; a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
   a.hx = 1;
   a.stats = stats;
@@ -656,10 +696,11 @@ static int wino1d_entry(const float* x, const void* U, const float* bias, const 
   return conv_wino1d_launch(a, ipdm_stream(stream));
 }
 
-extern "C" int ipdm_conv2d_wino1d_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
-                                      float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int pool2,
-                                      const ipdm_conv_ext_t* ext, void* stream) {
-  return wino1d_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, pool2, nullptr, ext, stream);
+extern "C" int ipdm_conv2d_wino1d_f32(const float* x, const void* U, const float* bias, const float* coef, int act,
+                                      const float* residual, float* out, float* out_act, int act_out, int B, int Cin, int Cout,
+                                      int H, int W, int pool2, const ipdm_conv_ext_t* ext, void* stream) {
+  IPDM_REQUIRE(coef || act == IPDM_ACT_NONE);
+  return wino1d_entry(x, U, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, H, W, pool2, nullptr, ext, stream);
 }
 
 // statistics epilogue: partials per plane (0: the layer shape is not served) and the call that fills stats[B][Cout][partials][3]
@@ -668,9 +709,10 @@ extern "C" int ipdm_conv2d_wino1d_stats_partials(int Cin, int Cout, int H, int W
   return ((W + 2 * Y_TX - 1) / (2 * Y_TX)) * ((H + Y_ROWS - 1) / Y_ROWS);
 }
 
-extern "C" int ipdm_conv2d_wino1d_stats_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
-                                            float* out_act, int act_out, int B, int Cin, int Cout, int H, int W, int pool2,
-                                            float* stats, const ipdm_conv_ext_t* ext, void* stream) {
-  IPDM_REQUIRE(stats != nullptr && out != nullptr);
-  return wino1d_entry(x, U, bias, residual, out, out_act, act_out, B, Cin, Cout, H, W, pool2, stats, ext, stream);
+extern "C" int ipdm_conv2d_wino1d_stats_f32(const float* x, const void* U, const float* bias, const float* coef, int act,
+                                            const float* residual, float* out, float* out_act, int act_out, int B, int Cin,
+                                            int Cout, int H, int W, int pool2, float* stats, const ipdm_conv_ext_t* ext,
+                                            void* stream) {
+  IPDM_REQUIRE(stats != nullptr && out != nullptr && (coef || act == IPDM_ACT_NONE));
+  return wino1d_entry(x, U, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, H, W, pool2, stats, ext, stream);
 }

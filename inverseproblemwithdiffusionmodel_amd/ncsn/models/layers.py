@@ -86,6 +86,13 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
     def packed_wino1d(self):
         return self._cached("wino1d", ops.conv_wino1d_weight)
 
+    def fuses_input(self, x, coef):
+        """True when this layer takes act(InstanceNorm++(x)) as (raw x, coefficients): the 1-D Winograd kernel applies the affine +
+        ELU to the raw rows in its producer, so the normalised tensor is never written (IPDM_WINO1D_FIN=0: the separate pass)"""
+        return (ops.WINO1D_FIN and USE_WINOGRAD and ops.split_impl() and self.ndim == 2 and self.kernel_size == 3 and x.dim() == 4
+                and x.data_ptr() % 16 == 0 and (not ops.dynamic_range() or getattr(coef, "_ipdm_amax_bound", None) is not None)
+                and ops.wino1d_pays(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation))
+
     def packed(self):
         if self.full_range and ops.CONV_IMPL == "hx2":
             return self._cached("direct_bx3", lambda w: ops.conv_weight(w, impl="bx3"))
@@ -105,6 +112,10 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
         produce = dyn and feeds_conv
         if in_amax is None and dyn and coef is None and act == ops.ACT_NONE:
             in_amax = ops.in_amax_for(x)
+        if coef is not None and act == ops.ACT_ELU and out is None and self.fuses_input(x, coef):
+            return ops.conv2d_wino_bx3(x, self.packed_wino1d(), bias, residual, act_out=act_out, raw=raw, want_stats=want_stats,
+                                       in_amax=getattr(coef, "_ipdm_amax_bound", None) if dyn else None, want_amax=produce,
+                                       res_second=res_second, coef=coef, act=act)
         if (self.ndim == 2 and self.kernel_size == 3 and self.dilation == 1 and act == ops.ACT_NONE
                 and residual is None and out is None and act_out == ops.ACT_NONE and raw and x.dim() == 4
                 and (self.in_planes <= 3 or (self.out_planes <= 3 and coef is None))
@@ -166,7 +177,7 @@ class ConvMeanPool(nn.Module):
             return self.conv(ops.meanpool2(inputs), feeds_conv=feeds_conv)
         return ops.meanpool2(self.conv(inputs, feeds_conv=feeds_conv))
 
-    def fused(self, inputs, residual=None, act_out=ops.ACT_NONE, feeds_conv=True):
+    def fused(self, inputs, residual=None, act_out=ops.ACT_NONE, feeds_conv=True, coef=None, act=ops.ACT_NONE):
         """3x3 ConvMeanPool (+ pooled-size residual, + activated copy) in ONE launch: the Winograd kernel's 2x2 output tile
         is the pooling window.  -> out or (out, out_act); None where the pooled epilogue is not built for this layer."""
         c = self.conv
@@ -177,6 +188,13 @@ class ConvMeanPool(nn.Module):
         one_d = (inputs.data_ptr() % 16 == 0 and act_out in (ops.ACT_NONE, ops.ACT_ELU, ops.ACT_COPY) and ops.WINO1D_STATS
                  and ops.wino1d_pays(c.in_planes, c.out_planes, inputs.shape[2], inputs.shape[3], 1))
         try:
+            if coef is not None:                         # fused input: the 1-D kernel's only (the caller asked c.fuses_input)
+                if not one_d:
+                    return None
+                return ops.conv2d_wino_bx3(inputs, c.packed_wino1d(), None if c.bias is None else c.bias.data, residual,
+                                           act_out=act_out, pool2=True, want_stats=True,
+                                           in_amax=getattr(coef, "_ipdm_amax_bound", None) if ops.dynamic_range() else None,
+                                           want_amax=ops.dynamic_range() and feeds_conv, coef=coef, act=act)
             return ops.conv2d_wino_bx3(inputs, c.packed_wino1d() if one_d else c.packed_wino_bx3(),
                                        None if c.bias is None else c.bias.data, residual,
                                        act_out=act_out, pool2=True, want_stats=True,     # a block's result: normalised next
@@ -352,19 +370,37 @@ class ResidualBlock(nn.Module):
         stage, whose result the next stage's shortcut convolution and the RefineNet branch read (the others' results meet
         normalisations and residual adds only: no maxima needed)."""
         code = _act_code(self.non_linearity)
-        h = self.conv1(self.normalize1(x, code), want_stats=True, feeds_conv=False)
-        a2 = self.normalize2(h, code)
+        h = self._norm_act_conv(self.normalize1, self.conv1, x, code, want_stats=True, feeds_conv=False)
+        a2 = None                                                # (act(normalize2(h)): materialised only where no kernel fuses it)
         if self.output_dim == self.input_dim and self.resample is None:
             shortcut = x
         else:
             shortcut = self.shortcut(x, feeds_conv=False)          # (a residual operand only)
         if isinstance(self.conv2, ConvMeanPool):
-            fused = self.conv2.fused(a2, residual=shortcut, act_out=code if want_act else ops.ACT_NONE, feeds_conv=want_act)
+            plain_norm = isinstance(self.normalize2, InstanceNorm2dPlus) and self.conv2.conv.ndim == 2
+            coef2 = self.normalize2.coef(h) if plain_norm else None
+            fin = plain_norm and code == ops.ACT_ELU and self.conv2.conv.fuses_input(h, coef2)
+            a2 = h if fin else (ops.affine_act(h, coef2, code) if plain_norm else self.normalize2(h, code))
+            fused = self.conv2.fused(a2, residual=shortcut, act_out=code if want_act else ops.ACT_NONE, feeds_conv=want_act,
+                                     coef=coef2 if fin else None, act=code if fin else ops.ACT_NONE)
             if fused is not None:                        # conv + 2x2 mean + shortcut (+ activated copy): one launch
                 return fused
+            if fin:
+                a2 = ops.affine_act(h, coef2, code)
             out = ops.add(shortcut, self.conv2(a2))
             return (out, ops.act(out, code)) if want_act else out
         # the block's result is what the next block normalises first
         if want_act:
-            return self.conv2(a2, residual=shortcut, act_out=code, want_stats=True)
-        return self.conv2(a2, residual=shortcut, want_stats=True, feeds_conv=False)
+            return self._norm_act_conv(self.normalize2, self.conv2, h, code, residual=shortcut, act_out=code, want_stats=True)
+        return self._norm_act_conv(self.normalize2, self.conv2, h, code, residual=shortcut, want_stats=True, feeds_conv=False)
+
+    @staticmethod
+    def _norm_act_conv(norm, conv, x, code, **kw):
+        """conv(act(norm(x))): one launch where the convolution kernel takes the normalisation's coefficients (Conv2d.fuses_input),
+        else the affine + activation pass and the convolution"""
+        if code == ops.ACT_ELU and isinstance(conv, Conv2d) and conv.ndim == 2 and isinstance(norm, InstanceNorm2dPlus):
+            coef = norm.coef(x)
+            if conv.fuses_input(x, coef):
+                return conv(x, coef=coef, act=code, **kw)
+            return conv(ops.affine_act(x, coef, code), **kw)
+        return conv(norm(x, code), **kw)

@@ -1194,6 +1194,10 @@ def conv_wino1d_weight(w):
 
 WINO1D = os.environ.get("IPDM_WINO1D", "1") != "0"          # 0: the 2-D Winograd kernel everywhere (A/B, fallback)
 WINO1D_STATS = os.environ.get("IPDM_WINO1D_STATS", "1") != "0"      # the launches with a statistics epilogue too (tuning)
+# InstanceNorm++ + ELU of the input inside the 1-D kernel's producer instead of the affine + activation pass: built, tested, and
+# measured SLOWER on MI355X (17.24 -> 17.68 ms per iteration, same box: +1.1 ms of convolution for 0.8 ms of passes removed -- the
+# exponentials and selects in a 256-register kernel cost more than 8 bytes per element at the HBM roof), so off by default
+WINO1D_FIN = os.environ.get("IPDM_WINO1D_FIN", "0") != "0"
 
 
 def wino1d_pays(Cin, Cout, H, W, dilation=1):
@@ -1214,7 +1218,7 @@ def conv_wino_bx3_supported(Cin, Cout, H, W, dilation=1):
 
 
 def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dilation=1, pool2=False, want_stats=False,
-                    in_amax=None, out_scale=1.0, want_amax=False, res_second=False):
+                    in_amax=None, out_scale=1.0, want_amax=False, res_second=False, coef=None, act=ACT_NONE):
     """3x3 convolution through the split-bf16 Winograd kernel (same output options as conv2d).
     res_second (needs residual, act_out (ACT_COPY = none) and raw): -> (conv + bias, act_out(conv + bias + residual)).
     pool2: the ConvMeanPool form -- outputs (and the residual) are [B, Cout, H/2, W/2] 2x2 means of the convolution;
@@ -1225,6 +1229,8 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
     B, Cin, H, W = x.shape
     amax_t = None
     if U.fmt == "hx2" and in_amax is not None:
+        if in_amax is True and coef is not None:
+            raise ValueError("conv2d_wino_bx3: with a fused input the maxima are the coefficient kernel's bound, not max |x|")
         amax_t = absmax_per_image(x) if in_amax is True else in_amax
     bias_per_image = bias is not None and bias.dim() == 2
     if bias_per_image and (tuple(bias.shape) != (B, U.Cout) or bias.stride(1) != 1):
@@ -1246,6 +1252,13 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
         raise ValueError("conv2d_wino_bx3: weight blob does not match the input")
     if one_d and (dilation != 1 or U.fmt != "hx2"):
         raise ValueError("conv2d_wino_bx3: the 1-D Winograd blob serves undilated f16x2 launches only")
+    if coef is not None or act != ACT_NONE:
+        # fused input act(InstanceNorm++(x)) (coef from instnorm_plus_coef): the 1-D kernel's producer applies it to the raw rows
+        if not one_d or coef is None or act != ACT_ELU:
+            raise ValueError("conv2d_wino_bx3: a fused input (coef + ACT_ELU) is the 1-D Winograd kernel's only")
+        coef = _gpu(coef, torch.float32, "coef")
+        if tuple(coef.shape) != (B, Cin, 3):
+            raise ValueError(f"conv2d_wino_bx3: coef {tuple(coef.shape)} != {(B, Cin, 3)}")
     if res_second and (residual is None or act_out == ACT_NONE or not raw):
         raise ValueError("conv2d_wino_bx3: res_second needs a residual and both outputs (act_out, e.g. ACT_COPY; raw=True)")
     Cout = U.Cout
@@ -1289,7 +1302,7 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
                 int(bool(pool2)))
         am = (ext_of(b0, b1),)
         if one_d:
-            a1 = args[:-2] + args[-1:]                  # (no dilation argument)
+            a1 = args[:3] + (_ptr(None if coef is None else coef[b0:b1]), act) + args[3:-2] + args[-1:]   # (+ fused input, no dilation)
             if part is not None:
                 call("ipdm_conv2d_wino1d_stats_f32", *a1, _ptr(part[b0:b1]), *am, _stream())
             else:

@@ -46,7 +46,8 @@ for idx, (cnt, ci, co, hw, dil) in enumerate(SHAPES):
     flop = 2.0 * B * hw * hw * ci * co * 9
     t_m = 1e9 if NO_MIOPEN else timeit(lambda: F.conv2d(x, w, bias, padding=dil, dilation=dil))
     if BX3 and WINO and ops.conv_wino_bx3_supported(ci, co, hw, hw, dil):
-        Uq = ops.conv_wino_bx3_weight(w, fmt=FMT)
+        one_d = FMT == "hx2" and os.environ.get("BENCH_W1D", "1") == "1" and dil == 1 and ops.wino1d_pays(ci, co, hw, hw)
+        Uq = ops.conv_wino1d_weight(w) if one_d else ops.conv_wino_bx3_weight(w, fmt=FMT)    # the layer dispatch's choice
         t_o = timeit(lambda: ops.conv2d_wino_bx3(x, Uq, bias, dilation=dil))
         out = ops.conv2d_wino_bx3(x, Uq, bias, dilation=dil)
         ref64 = F.conv2d(x[:2].double(), w.double(), bias.double(), padding=dil, dilation=dil)

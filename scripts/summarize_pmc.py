@@ -37,7 +37,7 @@ json.dump({"hbm_bytes_per_launch": per_launch, "launches_profiled": tot_n,
            "conv_impl": os.environ.get("IPDM_CONV_IMPL", "hx2"), "measured_at_commit": commit,
            "measured_on": datetime.date.today().isoformat(), "tag": tag,
            "fetch_KiB_raw_total": tot_f, "write_KiB_raw_total": tot_w,
-           "note": "mean over all convolution-kernel launches (conv_bx3_kernel, conv_wino_bx3_kernel; conv_mfma_kernel / conv_wino_kernel with IPDM_CONV_IMPL=f32) of bench.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+           "note": "mean over all convolution-kernel launches (conv_bx3_kernel, conv_wino1d_kernel, conv_wino_bx3_kernel; conv_mfma_kernel / conv_wino_kernel with IPDM_CONV_IMPL=f32) of bench.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                    "(gfx950 FETCH_SIZE halving corrected per MI355X_MICROARCH.md)"},
           open("profiles/conv_hbm_traffic.json", "w"), indent=1)
 print(open("profiles/conv_hbm_traffic.json").read())

@@ -225,3 +225,67 @@ def test_wino1d_layer_dispatch(ops, monkeypatch):
     assert kinds == [True, False]
     assert (y1 - y2).abs().max() <= 1e-6 * y2.abs().max()
     assert tuple(small.shape) == (2, 128, 16, 16)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,pool", [(2, 64, 128, 16, 64, False), (3, 32, 128, 40, 36, False), (2, 128, 128, 64, 64, False),
+                                                 (2, 64, 128, 34, 44, True)])
+def test_wino1d_fused_input_norm_and_elu(ops, B, Cin, Cout, H, W, pool):
+    """the input as (raw x, InstanceNorm++ coefficients): ELU((x - mu) * scale + shift) applied in the producer, the padding kept
+    at zero (ragged blocks: rows and columns beyond the image) -- against the separate affine + activation pass followed by the
+    same kernel, and against float64; statistics, residual, activated copy and the dynamic range (the coefficient bound) ride
+    along"""
+    gen = torch.Generator().manual_seed(51)
+    x = (torch.randn(B, Cin, H, W, generator=gen) * 3 + 1).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.1).cuda()
+    b = torch.randn(Cout, generator=gen).cuda()
+    oh, ow = (H // 2, W // 2) if pool else (H, W)
+    r = torch.randn(B, Cout, oh, ow, generator=gen).cuda()
+    alpha, gamma, beta = (torch.randn(Cin, generator=gen).cuda() for _ in range(3))
+    U = ops.conv_wino1d_weight(w)
+    with ops.amax_scope():
+        coef = ops.instnorm_plus_coef(x, alpha, gamma, beta)
+        bound = getattr(coef, "_ipdm_amax_bound", None)
+        a = ops.affine_act(x, coef, ops.ACT_ELU)
+        y_sep, ya_sep = ops.conv2d_wino_bx3(a, U, b, r, act_out=ops.ACT_ELU, pool2=pool, in_amax=bound)
+        y, ya = ops.conv2d_wino_bx3(x, U, b, r, act_out=ops.ACT_ELU, pool2=pool, want_stats=True, in_amax=bound, coef=coef,
+                                    act=ops.ACT_ELU)
+    ad = F.elu((x.double() - coef[..., 0, None, None].double()) * coef[..., 1, None, None].double() + coef[..., 2, None, None].double())
+    conv = F.conv2d(ad, w.double(), b.double(), padding=1)
+    ref = (conv[..., ::2, ::2] + conv[..., 1::2, ::2] + conv[..., ::2, 1::2] + conv[..., 1::2, 1::2]) / 4 if pool else conv
+    ref = ref + r.double()
+    assert (y.double() - ref).abs().max() <= 2e-6 * ref.abs().max()
+    assert (y - y_sep).abs().max() <= 2e-6 * y_sep.abs().max()          # (the fused affine contracts one multiply-add)
+    assert (ya - ya_sep).abs().max() <= 2e-6 * y_sep.abs().max()
+    assert hasattr(y, "_ipdm_partials")
+    with pytest.raises(ValueError):
+        ops.conv2d_wino_bx3(x, ops.conv_wino_hx2_weight(w), b, coef=coef, act=ops.ACT_ELU)      # the 2-D kernel has no fused input
+    with pytest.raises(ValueError):
+        ops.conv2d_wino_bx3(x, U, b, coef=coef, act=ops.ACT_RELU)
+
+
+def test_residual_block_fused_norms_match_separate_passes(ops, monkeypatch):
+    """ResidualBlock (plain and down-sampling): with the normalisations applied inside the convolutions the block's result equals
+    the separate-pass form to rounding"""
+    from inverseproblemwithdiffusionmodel_amd.ncsn.models import layers
+    if ops.CONV_IMPL != "hx2":
+        pytest.skip("f16x2 family")
+    gen = torch.Generator().manual_seed(52)
+    x = torch.randn(2, 128, 32, 64, generator=gen).cuda()
+    for resample, cout in ((None, 128), ("down", 256)):
+        blk = layers.ResidualBlock(128, cout, resample=resample, act=torch.nn.ELU()).cuda()
+        for p_ in blk.parameters():
+            p_.data = (0.2 * torch.randn(p_.shape, generator=gen)).cuda() + (1.0 if p_.dim() == 1 else 0.0)
+        with torch.no_grad():
+            monkeypatch.setattr(ops, "WINO1D_FIN", False)
+            with ops.amax_scope():
+                y0 = blk(x)
+            monkeypatch.setattr(ops, "WINO1D_FIN", True)
+            ops.CONV_TRACE = []
+            try:
+                with ops.amax_scope():
+                    y1 = blk(x)
+                n = len(ops.CONV_TRACE)
+            finally:
+                ops.CONV_TRACE = None
+        assert n >= 2
+        assert (y1 - y0).abs().max() <= 5e-6 * y0.abs().max()
