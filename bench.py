@@ -355,12 +355,13 @@ def main():
             out["roofline"] = dict({
                 "bound": "mfma", "achieved": executed_tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": executed_tflops / PEAK_BF16_MFMA_TFLOPS,
-                "kernel": "conv_wino_bx3_wide_kernel (Winograd F(2x2,3x3)) + conv_bx3_kernel<...> (direct): fp32 convolution as "
+                "kernel": "conv_wino1d_kernel (1-D Winograd F(2,3) along x, filter rows as K) + conv_wino_bx3_wide_kernel (Winograd "
+                          "F(2x2,3x3), 16-pixel stages) + conv_bx3_kernel<...> (direct): fp32 convolution as "
                           + ("3 x v_mfma_f32_32x32x16_f16 on two-piece fp16 operand splits" if ops.CONV_IMPL == "hx2" else
                              "6 x v_mfma_f32_32x32x16_bf16 on exact bf16x3 operand splits") + ", fp32 accumulate",
                 "mfma_per_fp32_product": mfma_per_product,
-                "achieved_note": "executed 16-bit MFMA FLOPs (mfma_per_fp32_product per fp32 multiply-add of the split, Winograd "
-                                 "launches at 16/36 of the direct multiply-adds) / measured conv time, against the dense "
+                "achieved_note": "executed 16-bit MFMA FLOPs (mfma_per_fp32_product per fp32 multiply-add of the split; 1-D Winograd "
+                                 "launches at 24/36, 2-D ones at 16/36 of the direct multiply-adds) / measured conv time, against the dense "
                                  "bf16 / fp16 MFMA peak (same rate)",
                 "algorithmic": {"achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS / mfma_per_product,
                                 "frac": achieved / (PEAK_BF16_MFMA_TFLOPS / mfma_per_product), "unit": "TFLOP/s",
@@ -369,6 +370,7 @@ def main():
                                         "conv time over the fp32-equivalent roof = 16-bit MFMA peak / MFMAs per product; "
                                         "frac_of_round2_roof prices the same rate against round 2's roof (peak / 6)"},
                 "bx3_launches": n_bx3, "winograd_launches": n_wino,
+                "winograd_1d_launches": sum(1 for r in reps[0] if r.get("wino1d")),
                 "fp32_mfma_peak_tflops": PEAK_FP32_MFMA_TFLOPS,
             }, **common)
         else:
