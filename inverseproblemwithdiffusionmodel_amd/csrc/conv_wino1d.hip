@@ -531,8 +531,16 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) {
             const unsigned ob = boff(c, nb, half * 2 + kk);
+#ifdef IPDM_W1D_NO_NT
+            if constexpr (W_OUT) *reinterpret_cast<vecv*>(out_b + ob) = ov[kk];
+#else
             if constexpr (W_OUT) __builtin_nontemporal_store(ov[kk], reinterpret_cast<vecv*>(out_b + ob));
+#endif
+#ifdef IPDM_W1D_ACT_NT
+            if constexpr (W_ACT) __builtin_nontemporal_store(ev[kk], reinterpret_cast<vecv*>(act_b + ob));
+#else
             if constexpr (W_ACT) *reinterpret_cast<vecv*>(act_b + ob) = ev[kk];
+#endif
           }
         }
       }
