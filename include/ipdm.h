@@ -452,6 +452,15 @@ int ipdm_conv2d_wino_hx2_f32(const float* x, const void* U, const float* bias, c
 int64_t ipdm_conv_wino1d_weight_bytes(int Cout, int Cin);
 int ipdm_conv_wino1d_pack_weight(const float* w /* [Cout][Cin][3][3] */, void* U, int Cout, int Cin, void* stream);
 int ipdm_conv2d_wino1d_supported(int Cin, int Cout, int H, int W);
+/* 3x3x3 convolution of volumes [B][C][D][H][W] on the same kernel: the depth taps are further K chunks (36 weight positions; blob
+ * from ipdm_conv_wino1d_pack_weight3d, w [Cout][Cin][3][3][3]); planes of 12 pixels or less go two depth slices per row block.
+ * Undilated, Cin % 32 == 0, Cout % 128 == 0, W % 4 == 0 and (W <= 12 or W >= 16): ipdm_conv3d_wino1d_supported. */
+int64_t ipdm_conv_wino1d_weight_bytes3d(int Cout, int Cin);
+int ipdm_conv_wino1d_pack_weight3d(const float* w, void* U, int Cout, int Cin, void* stream);
+int ipdm_conv3d_wino1d_supported(int Cin, int Cout, int D, int H, int W);
+int ipdm_conv3d_wino1d_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
+                           float* out_act, int act_out, int B, int Cin, int Cout, int D, int H, int W,
+                           const ipdm_conv_ext_t* ext, void* stream);
 /* coef != NULL: the input is act(InstanceNorm++(x)) -- coef [B][Cin][3] from ipdm_instnorm_plus_coef_f32, act = IPDM_ACT_ELU --
  * applied inside the kernel (as ipdm_conv2d_hx2_f32's fused input); ext->in_amax is then the coefficient kernel's bound. */
 int ipdm_conv2d_wino1d_f32(const float* x, const void* U, const float* bias, const float* coef, int act,

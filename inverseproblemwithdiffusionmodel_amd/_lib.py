@@ -104,6 +104,10 @@ SIGNATURES = {
     "ipdm_conv_wino1d_weight_bytes": [c_int, c_int],
     "ipdm_conv_wino1d_pack_weight": [P, P, c_int, c_int, P],
     "ipdm_conv2d_wino1d_supported": [c_int, c_int, c_int, c_int],
+    "ipdm_conv_wino1d_weight_bytes3d": [c_int, c_int],
+    "ipdm_conv_wino1d_pack_weight3d": [P, P, c_int, c_int, P],
+    "ipdm_conv3d_wino1d_supported": [c_int, c_int, c_int, c_int, c_int],
+    "ipdm_conv3d_wino1d_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "ipdm_conv2d_wino1d_f32": [P, P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "ipdm_conv2d_wino1d_stats_partials": [c_int, c_int, c_int, c_int],
     "ipdm_conv2d_wino1d_stats_f32": [P, P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P],
@@ -127,7 +131,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"ipdm_build_arch": c_char_p, "ipdm_fft2c_workspace_bytes": c_int64, "ipdm_sense_workspace_bytes": c_int64, "ipdm_conv_bx3_weight_bytes": c_int64,
              "ipdm_conv_wino_bx3_weight_bytes": c_int64, "ipdm_conv_hx2_weight_bytes": c_int64,
-             "ipdm_conv_wino_hx2_weight_bytes": c_int64, "ipdm_conv_wino1d_weight_bytes": c_int64}
+             "ipdm_conv_wino_hx2_weight_bytes": c_int64, "ipdm_conv_wino1d_weight_bytes": c_int64, "ipdm_conv_wino1d_weight_bytes3d": c_int64}
 
 IPDM_EINVAL = -1
 IPDM_EUNSUPPORTED = -2

@@ -41,7 +41,9 @@ static_assert(Y_STAGE <= 2 * Y_M && Y_LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr float HX1_PRESCALE = 0.5f;                 // the 1-D input transform at most doubles a value
 constexpr int Y_QC = 10, Y_RC4 = 40, Y_QN = 100;     // quads / floats per raw row, quads per channel
 
-__device__ __forceinline__ float wino1d_U(const float* g, int p) {       // p = ky*4 + xi
+__device__ __forceinline__ float wino1d_U(const float* g, int p) {       // p = (kz*3 + ky)*4 + xi; g: the filter's 9 (or 27) taps
+  g += (p / 12) * 9;
+  p %= 12;
   const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
   const int ky = p >> 2, xi = p & 3;
   return G[xi][0] * g[ky * 3 + 0] + G[xi][1] * g[ky * 3 + 1] + G[xi][2] * g[ky * 3 + 2];
@@ -49,12 +51,13 @@ __device__ __forceinline__ float wino1d_U(const float* g, int p) {       // p = 
 
 // one workgroup per output channel: inv_scale[co] = 2^-k with max |U| * 2^k in [2^13, 2^14), times 1 / HX1_PRESCALE
 __global__ __launch_bounds__(256) void wino1d_scale_kernel(const float* __restrict__ w, float* __restrict__ inv_scale, int Cout,
-                                                           int Cin, int n_co_pad) {
+                                                           int Cin, int n_co_pad, int npos) {
   __shared__ float red[256];
   const int co = blockIdx.x;
   float m = 0.f;
   if (co < Cout)
-    for (int i = threadIdx.x; i < Cin * 12; i += 256) m = fmaxf(m, fabsf(wino1d_U(w + ((size_t)co * Cin + i / 12) * 9, i % 12)));
+    for (int i = threadIdx.x; i < Cin * npos; i += 256)
+      m = fmaxf(m, fabsf(wino1d_U(w + ((size_t)co * Cin + i / npos) * (npos / 12 * 9), i % npos)));
   red[threadIdx.x] = m;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) {
@@ -71,8 +74,8 @@ __global__ __launch_bounds__(256) void wino1d_scale_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void wino1d_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
                                                             const float* __restrict__ inv_scale, int Cout, int Cin, int n_cc,
-                                                            int n_ct) {
-  const int64_t total = (int64_t)12 * n_cc * n_ct * 512;
+                                                            int n_ct, int npos) {
+  const int64_t total = (int64_t)npos * n_cc * n_ct * 512;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int q = (int)(i & 7), r = (int)((i >> 3) & 31), h = (int)((i >> 8) & 1);
     const int64_t rest = i >> 9;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void wino1d_weight_kernel(const float* __restr
     const int p = (int)(rest / ((int64_t)n_ct * n_cc));
     const int co = ct * 32 + r, ci = cc * 16 + 8 * h + q;
     float v = 0.f;
-    if (co < Cout && ci < Cin) v = wino1d_U(w + ((size_t)co * Cin + ci) * 9, p) * (1.f / (inv_scale[co] * HX1_PRESCALE));
+    if (co < Cout && ci < Cin) v = wino1d_U(w + ((size_t)co * Cin + ci) * (npos / 12 * 9), p) * (1.f / (inv_scale[co] * HX1_PRESCALE));
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)(v - (float)hi);
     const int64_t base = rest * 2 * 512 + h * 256 + r * 8 + q;
@@ -98,7 +101,10 @@ __global__ __launch_bounds__(256) void wino1d_weight_kernel(const float* __restr
 // FIN: the input is act(InstanceNorm++(x)) of a raw tensor x (a.coef [B][Cin][3]: (x - mu) * scale + shift, then ELU): applied to the raw
 // rows on their way through the producer's registers -- every raw value once per row item, the padding kept at zero -- instead of an
 // affine + activation pass that writes the normalised tensor and reads it back (8 bytes of HBM per element)
-template <int OUTS, bool STATS = false, bool POOL = false, bool FIN = false>
+// VOL: 3x3x3 convolution of volumes [B][C][D][H][W] -- the depth taps are further K chunks (chunk = (kz, 16 channels): the raw rows of
+// plane z + kz - 1, hardware-zeroed outside the volume; 36 weight positions), and planes of 12 pixels or less go TWO per row block
+// (depth slices z, z+1 side by side: the producer zeroes the two neighbour values that cross the seam)
+template <int OUTS, bool STATS = false, bool POOL = false, bool FIN = false, bool VOL = false>
 __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_tiles) {
   extern __shared__ __align__(16) float lds[];
   unsigned* const ldsw = reinterpret_cast<unsigned*>(lds);
@@ -109,7 +115,11 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
   const int xi = wave & 3, chh = wave >> 2;
   const int HW = a.H * a.W;
   const int n_cc = a.Cin / Y_KC, n_ct = a.Cout / 32;
-  const int n_chunks = n_cc;                                   // even, >= 2 (launcher)
+  static_assert(!VOL || (!STATS && !POOL && !FIN), "VOL: plain epilogues");
+  const int n_chunks = VOL ? 3 * n_cc : n_cc;                  // even, >= 2 (launcher)
+  const int CS = VOL ? a.D * HW : HW;                          // channel stride of input / output
+  const bool pack = VOL && a.W <= 12;                          // two depth slices per row block
+  const int seam = a.W >> 1;                                   // pack: first pixel pair of the second slice
   unsigned long long t0 = 0, t1 = 0, t_loop = 0, t_epi = 0, tq = 0;   // tuning stamps (a.dbg)
 #ifdef IPDM_W1D_TRACE
   unsigned long long te[4] = {0, 0, 0, 0};                            // epilogue phases: exchange stores, barrier, transform + stores, barrier
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
     for (int i = 0; i < g * (a.ksplit - 1); ++i) __builtin_amdgcn_s_sleep(8);          // ~8 x 64 cycles each
   }
 
-  struct Geo { int b, y0, x0, cob; };
+  struct Geo { int b, y0, x0, cob, z; };
   auto geo_of = [&](int L) {
     Geo g;
     g.cob = L % a.co_tiles;
@@ -140,37 +150,77 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
     t /= a.tiles_x;
     g.y0 = (t % a.tiles_y) * Y_ROWS;
     g.x0 = tx * (2 * Y_TX);
-    g.b = t / a.tiles_y;
+    t /= a.tiles_y;
+    g.z = 0;
+    if constexpr (VOL) {
+      const int nz = pack ? (a.D + 1) >> 1 : a.D;
+      g.z = (t % nz) * (pack ? 2 : 1);
+      t /= nz;
+    }
+    g.b = t;
     return g;
   };
 
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x), 0, (int)((size_t)a.B * a.Cin * HW * 4), 0x00020000);
+      const_cast<float*>(a.x), 0, (int)((size_t)a.B * a.Cin * CS * 4), 0x00020000);
   float* const rs = lds + Y_STAGE;
 
   // raw stage: wave w fetches channels 2w, 2w+1 of a chunk (2 x 100 quads) into its own block, four 16-byte LDS-DMA instructions
-  int dma_off[4];
+  int dma_off[4];                                               // VOL: without the plane's offset (it changes with the chunk's depth tap)
   int dma_b = 0;
+  [[maybe_unused]] int dma_z = 0, dma_isb = 0;                  // VOL: the tile's first depth slice; bit k: piece k reads the SECOND slice
   auto set_dma_geo = [&](const Geo& g) {
     dma_b = g.b;
+    if constexpr (VOL) {
+      dma_z = g.z;
+      dma_isb = 0;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int e = k * 64 + lane;
       const int cl = e / Y_QN, qq = e - cl * Y_QN;
       const int cin = 2 * wave + cl;
       const int rr = qq / Y_QC, qc = qq - rr * Y_QC;
-      const int gy = g.y0 - 1 + rr, gx0 = g.x0 - 4 + 4 * qc;
-      const bool ok = e < 2 * Y_QN && gy >= 0 && gy < a.H && gx0 >= 0 && gx0 < a.W;
-      dma_off[k] = ok ? (cin * HW + gy * a.W + gx0) * 4 : 0x40000000;
+      const int gy = g.y0 - 1 + rr;
+      int gx0 = g.x0 - 4 + 4 * qc;
+      bool okx = gx0 >= 0 && gx0 < a.W;
+      if constexpr (VOL) {
+        if (pack) {                                             // raw columns 4 .. 4+W: slice z, 4+W .. 4+2W: slice z+1
+          const bool in_b = gx0 >= a.W && gx0 < 2 * a.W;
+          okx = okx || in_b;
+          gx0 -= in_b ? a.W : 0;
+          dma_isb |= in_b ? 1 << k : 0;
+        }
+      }
+      const bool ok = e < 2 * Y_QN && gy >= 0 && gy < a.H && okx;
+      dma_off[k] = ok ? (cin * CS + gy * a.W + gx0) * 4 : 0x40000000;
     }
   };
   auto issue_dma = [&](int chunk) {
-    [[maybe_unused]] const int soff = (int)(((size_t)dma_b * a.Cin + chunk * Y_KC) * HW * 4);
+    int cc = chunk;
+    [[maybe_unused]] int off_a = 0, off_b = 0;
+    [[maybe_unused]] bool ok_a = true, ok_b = false;
+    if constexpr (VOL) {
+      const int kz = chunk / n_cc;
+      cc = chunk - kz * n_cc;
+      const int za = dma_z + kz - 1, zb = za + 1;
+      ok_a = (unsigned)za < (unsigned)a.D;
+      ok_b = pack && (unsigned)zb < (unsigned)a.D && dma_z + 1 < a.D;
+      off_a = za * HW * 4;
+      off_b = zb * HW * 4;
+    }
+    [[maybe_unused]] const int soff = (int)(((size_t)dma_b * a.Cin + cc * Y_KC) * CS * 4);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      int off = dma_off[k];
+      if constexpr (VOL) {
+        const bool isb = (dma_isb >> k) & 1;
+        const bool ok = off != 0x40000000 && (isb ? ok_b : ok_a);
+        off = ok ? off + (isb ? off_b : off_a) : 0x40000000;
+      }
 #if defined(__HIP_DEVICE_COMPILE__)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(rs + (wave * 4 + k) * 256), 16,
-                                               dma_off[k], soff, 0, 0);
+                                               off, soff, 0, 0);
 #endif
     }
   };
@@ -239,8 +289,15 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
     const float ra = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r.qa.x), 0x101, 0xf, 0xf, true));
     const float lb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r.qb.y), 0x111, 0xf, 0xf, true));
     const float rb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r.qb.x), 0x101, 0xf, 0xf, true));
-    const float a0 = pfirst ? r.ea : la, a3 = plast ? r.ea : ra;
-    const float b0 = pfirst ? r.eb : lb, b3 = plast ? r.eb : rb;
+    float a0 = pfirst ? r.ea : la, a3 = plast ? r.ea : ra;
+    float b0 = pfirst ? r.eb : lb, b3 = plast ? r.eb : rb;
+    if constexpr (VOL) {
+      if (pack) {                                               // neighbours across the seam belong to the other slice: padding
+        const bool s_l = pt == seam, s_r = pt == seam - 1;
+        a0 = s_l ? 0.f : a0; b0 = s_l ? 0.f : b0;
+        a3 = s_r ? 0.f : a3; b3 = s_r ? 0.f : b3;
+      }
+    }
     va[0] = a0 - r.qa.y; va[1] = r.qa.x + r.qa.y; va[2] = r.qa.y - r.qa.x; va[3] = r.qa.x - a3;
     vb[0] = b0 - r.qb.y; vb[1] = r.qb.x + r.qb.y; vb[2] = r.qb.y - r.qb.x; vb[3] = r.qb.x - b3;
   };
@@ -267,8 +324,13 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
   // ---- consumer operands ----
   const uint4* wq = reinterpret_cast<const uint4*>(a.wt);
   const size_t pos_stride = (size_t)n_cc * n_ct * 128;
-  auto load_A = [&](uint4 (&fr)[2][2], int ky, int cc, int cob) {
-    const uint4* base = wq + (size_t)(ky * 4 + xi) * pos_stride + ((size_t)cc * n_ct + cob * 4 + chh * 2) * 128 + lane;
+  auto load_A = [&](uint4 (&fr)[2][2], int ky, int chunk, int cob) {
+    int cc = chunk, kz = 0;
+    if constexpr (VOL) {
+      kz = chunk / n_cc;
+      cc = chunk - kz * n_cc;
+    }
+    const uint4* base = wq + (size_t)((kz * 3 + ky) * 4 + xi) * pos_stride + ((size_t)cc * n_ct + cob * 4 + chh * 2) * 128 + lane;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -404,16 +466,25 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
     float* const ms = lds + Y_S1;
     const int ecol = tid & 31, ecg = tid >> 5;                  // this thread: column, channels k*16 + ecg of the round's 64
     const int co0 = cur_g.cob * Y_CO;
-    const float* const scale_p = reinterpret_cast<const float*>(wq + 12 * pos_stride);
-    const int oHW = POOL ? HW >> 2 : HW, oW = POOL ? a.W >> 1 : a.W;     // the written tensor's plane / row
-    const size_t tile_base = (((size_t)cur_g.b * a.Cout + co0) * oHW + (size_t)(POOL ? cur_g.y0 >> 1 : cur_g.y0) * oW +
+    const float* const scale_p = reinterpret_cast<const float*>(wq + (VOL ? 36 : 12) * pos_stride);
+    const int oHW = POOL ? HW >> 2 : (VOL ? CS : HW), oW = POOL ? a.W >> 1 : a.W;     // the written tensor's channel stride / row
+    const size_t tile_base = (((size_t)cur_g.b * a.Cout + co0) * oHW + (size_t)cur_g.z * HW + (size_t)(POOL ? cur_g.y0 >> 1 : cur_g.y0) * oW +
                               (POOL ? cur_g.x0 >> 1 : cur_g.x0)) * 4;
-    unsigned eoff4 = 4u * (unsigned)(ecg * oHW + (POOL ? (ecol & 15) : (ecol >> 4) * oW + 2 * (ecol & 15)));
+    // pack: pixel pairs seam .. 2 seam - 1 are the second slice's pairs 0 .. seam - 1
+    const bool e_isb = pack && (ecol & 15) >= seam;
+    const int e_pair = e_isb ? (ecol & 15) - seam : (ecol & 15);
+    unsigned eoff4 = 4u * (unsigned)(ecg * oHW + (POOL ? (ecol & 15) : (ecol >> 4) * oW + 2 * e_pair + (e_isb ? HW : 0)));
     asm volatile("" : "+v"(eoff4));
     auto boff = [&](int c, int nb, int k) -> unsigned {
       return 4u * (unsigned)((((k >> 1) * 2 + c) * 32 + (k & 1) * 16) * oHW + (POOL ? nb : 2 * nb) * oW) + eoff4;
     };
-    auto in_range = [&](int nb) { return cur_g.y0 + 2 * nb + (ecol >> 4) < a.H && cur_g.x0 + 2 * (ecol & 15) < a.W; };
+    auto in_range = [&](int nb) {
+      const bool row_ok = cur_g.y0 + 2 * nb + (ecol >> 4) < a.H;
+      if constexpr (VOL) {
+        if (pack) return row_ok && (ecol & 15) < 2 * seam && (!e_isb || cur_g.z + 1 < a.D);
+      }
+      return row_ok && cur_g.x0 + 2 * (ecol & 15) < a.W;
+    };
     const bool has_res = a.residual != nullptr, has_bias = a.bias != nullptr;
     const bool elu = a.act_out == IPDM_ACT_ELU;                 // otherwise the activated copy is the identity (launcher)
     const float* const res_p = has_res ? a.residual : a.wt;
@@ -656,13 +727,13 @@ int conv_wino1d_launch(ConvArgs a, hipStream_t s) {
   return ipdm_launch_status();
 }
 
-int conv_wino1d_weights(const float* w, void* U, int Cout, int Cin, hipStream_t s) {
+int conv_wino1d_weights(const float* w, void* U, int Cout, int Cin, int npos, hipStream_t s) {
   const int n_cc = (Cin + 15) / 16, n_ct = (Cout + 31) / 32;
-  const int64_t total = (int64_t)12 * n_cc * n_ct * 512;
+  const int64_t total = (int64_t)npos * n_cc * n_ct * 512;
   float* inv_scale = reinterpret_cast<float*>(static_cast<char*>(U) + total * 2 * 2);
-  hipLaunchKernelGGL(wino1d_scale_kernel, dim3(n_ct * 32), dim3(256), 0, s, w, inv_scale, Cout, Cin, n_ct * 32);
+  hipLaunchKernelGGL(wino1d_scale_kernel, dim3(n_ct * 32), dim3(256), 0, s, w, inv_scale, Cout, Cin, n_ct * 32, npos);
   hipLaunchKernelGGL(wino1d_weight_kernel, dim3(ipdm_ew_grid(total, 256)), dim3(256), 0, s, w, (unsigned short*)U, inv_scale, Cout,
-                     Cin, n_cc, n_ct);
+                     Cin, n_cc, n_ct, npos);
   return ipdm_launch_status();
 }
 
@@ -677,7 +748,7 @@ extern "C" int64_t ipdm_conv_wino1d_weight_bytes(int Cout, int Cin) {
 
 extern "C" int ipdm_conv_wino1d_pack_weight(const float* w, void* U, int Cout, int Cin, void* stream) {
   IPDM_REQUIRE(w && U && Cout > 0 && Cin > 0);
-  return conv_wino1d_weights(w, U, Cout, Cin, ipdm_stream(stream));
+  return conv_wino1d_weights(w, U, Cout, Cin, 12, ipdm_stream(stream));
 }
 
 extern "C" int ipdm_conv2d_wino1d_supported(int Cin, int Cout, int H, int W) {
@@ -723,4 +794,84 @@ extern "C" int ipdm_conv2d_wino1d_stats_f32(const float* x, const void* U, const
                                             void* stream) {
   IPDM_REQUIRE(stats != nullptr && out != nullptr && (coef || act == IPDM_ACT_NONE));
   return wino1d_entry(x, U, bias, coef, act, residual, out, out_act, act_out, B, Cin, Cout, H, W, pool2, stats, ext, stream);
+}
+
+// ---- 3x3x3 convolution of volumes on the same kernel (VOL instantiations) ----------------------------------------------------
+namespace ipdm_conv {
+bool wino1d_vol_ok(const ConvArgs& a) {
+  if (!(a.D >= 1 && a.dil == 1 && a.Cin % (2 * Y_KC) == 0 && a.Cout % Y_CO == 0 && !a.coef && a.act == IPDM_ACT_NONE)) return false;
+  if (a.out_act && a.act_out != IPDM_ACT_ELU && a.act_out != IPDM_ACT_COPY) return false;
+  if (a.pool2 || a.stats) return false;
+  if ((size_t)a.B * a.Cin * a.D * a.H * a.W * 4 >= 0x3fffffffull) return false;            // buffer descriptor / padding marker
+  if ((size_t)a.D * a.H * a.W * Y_CO * 4 >= 0xffffffffull) return false;                   // 32-bit store offsets inside a channel block
+  // rows of 16 .. any pixels (a 32-pixel block each) or planes of 12 pixels or less (two depth slices per block)
+  return a.H >= 2 && a.W % 4 == 0 && (a.W <= 12 || a.W >= 16) && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
+}
+
+int conv_wino1d_vol_launch(ConvArgs a, hipStream_t s) {
+  const bool pack = a.W <= 12;
+  a.tiles_x = pack ? 1 : (a.W + 2 * Y_TX - 1) / (2 * Y_TX);
+  a.tiles_y = (a.H + Y_ROWS - 1) / Y_ROWS;
+  a.co_tiles = a.Cout / Y_CO;
+  a.ksplit = 1;
+  const int64_t nblk = (int64_t)a.B * (pack ? (a.D + 1) / 2 : a.D) * a.tiles_x * a.tiles_y * a.co_tiles;
+  if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* kernels[] = {reinterpret_cast<const void*>(conv_wino1d_kernel<1, false, false, false, true>),
+                             reinterpret_cast<const void*>(conv_wino1d_kernel<2, false, false, false, true>),
+                             reinterpret_cast<const void*>(conv_wino1d_kernel<3, false, false, false, true>)};
+    for (const void* k : kernels) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Y_LDS_BYTES);
+      if (e != hipSuccess) return (int)e;
+    }
+    attr_set = true;
+  }
+  int cus = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+    cus = 256;
+  const int per_xcd = (int)((nblk + 7) / 8);
+  const int S = per_xcd < cus / 8 ? per_xcd : cus / 8;
+  const int outs = (a.out ? 1 : 0) | (a.out_act ? 2 : 0);
+  if (outs == 3)
+    hipLaunchKernelGGL((conv_wino1d_kernel<3, false, false, false, true>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
+  else if (outs == 1)
+    hipLaunchKernelGGL((conv_wino1d_kernel<1, false, false, false, true>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
+  else
+    hipLaunchKernelGGL((conv_wino1d_kernel<2, false, false, false, true>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
+  return ipdm_launch_status();
+}
+}  // namespace ipdm_conv
+
+extern "C" int64_t ipdm_conv_wino1d_weight_bytes3d(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0) return -1;
+  return (int64_t)36 * ((Cin + 15) / 16) * ((Cout + 31) / 32) * 2048 + (int64_t)((Cout + 31) / 32) * 32 * 4;
+}
+
+extern "C" int ipdm_conv_wino1d_pack_weight3d(const float* w, void* U, int Cout, int Cin, void* stream) {
+  IPDM_REQUIRE(w && U && Cout > 0 && Cin > 0);
+  return conv_wino1d_weights(w, U, Cout, Cin, 36, ipdm_stream(stream));
+}
+
+extern "C" int ipdm_conv3d_wino1d_supported(int Cin, int Cout, int D, int H, int W) {
+  ConvArgs a;
+  a.x = nullptr; a.out = a.out_act = nullptr; a.act_out = IPDM_ACT_NONE; a.coef = nullptr; a.act = IPDM_ACT_NONE; a.dil = 1;
+  a.D = D; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.B = 1;
+  return wino1d_vol_ok(a) ? 1 : 0;
+}
+
+extern "C" int ipdm_conv3d_wino1d_f32(const float* x, const void* U, const float* bias, const float* residual, float* out,
+                                      float* out_act, int act_out, int B, int Cin, int Cout, int D, int H, int W,
+                                      const ipdm_conv_ext_t* ext, void* stream) {
+  IPDM_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(x && U && (out || out_act) && x != out && x != out_act);
+  ConvArgs a;
+  a.x = x; a.wt = (const float*)U; a.bias = bias; a.coef = nullptr; a.residual = residual; a.out = out; a.out_act = out_act;
+  a.act_out = act_out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dil = 1; a.act = IPDM_ACT_NONE;
+  a.D = D; a.kd = 3; a.tiles_x = a.tiles_y = a.co_tiles = 0; a.dbg = conv_debug_stamps();
+  a.hx = 1;
+  conv_apply_ext(a, ext, 1);
+  if (!wino1d_vol_ok(a)) return IPDM_EUNSUPPORTED;
+  return conv_wino1d_vol_launch(a, ipdm_stream(stream));
 }

@@ -135,6 +135,11 @@ class Conv2d(ops.PackedWeightMixin, nn.Module):
             return ops.conv2d_wino_bx3(x, self.packed_wino1d() if one_d else self.packed_wino_bx3(), bias, residual,
                                        act_out=act_out, raw=raw, dilation=self.dilation, want_stats=want_stats, in_amax=in_amax,
                                        want_amax=produce, res_second=res_second)
+        if (self.ndim == 3 and self.kernel_size == 3 and self.dilation == 1 and coef is None and act == ops.ACT_NONE and out is None
+                and x.dim() == 5 and x.data_ptr() % 16 == 0 and act_out in (ops.ACT_NONE, ops.ACT_ELU, ops.ACT_COPY)
+                and ops.wino1d_vol_pays(self.in_planes, self.out_planes, x.shape[2], x.shape[3], x.shape[4])):
+            return ops.conv3d(x, self._cached("wino1d_vol", ops.conv_wino1d_weight3d), bias, residual=residual, act_out=act_out,
+                              raw=raw, in_amax=in_amax, want_amax=produce, res_second=res_second)
         if self.ndim == 3:
             return ops.conv3d(x, self.packed(), bias, coef, act, residual, self.dilation, act_out=act_out, raw=raw,
                               in_amax=in_amax, want_amax=produce, res_second=res_second)

@@ -839,6 +839,11 @@ def conv2d_wino(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, dila
 def conv3d(x, wt, bias=None, coef=None, act=ACT_NONE, residual=None, dilation=1, act_out=ACT_NONE, raw=True, in_amax=None,
            want_amax=False, res_second=False):
     """x [B,Cin,D,H,W]; wt packed [27 or 1, Cin, Cout]; same fused input/output options as conv2d"""
+    if isinstance(wt, PackedBx3) and wt.kk == 36:                # conv_wino1d_weight3d: the 1-D Winograd kernel's volume form
+        if coef is not None or act != ACT_NONE or dilation != 1:
+            raise ValueError("conv3d: the 1-D Winograd blob serves undilated launches without a fused input")
+        return conv3d_wino1d(x, wt, bias, residual, act_out=act_out, raw=raw, in_amax=in_amax, want_amax=want_amax,
+                             res_second=res_second)
     if isinstance(wt, PackedBx3):
         return conv_bx3(x, wt, bias, coef, act, residual, dilation, act_out=act_out, raw=raw, in_amax=in_amax,
                         want_amax=want_amax, res_second=res_second)
@@ -1192,6 +1197,64 @@ def conv_wino1d_weight(w):
     return PackedBx3(blob, Cout, Cin, 12, "hx2")
 
 
+def conv_wino1d_weight3d(w):
+    """[Cout, Cin, 3, 3, 3] -> weights of the 1-D Winograd kernel's volume form (36 positions: depth tap x filter row x position)"""
+    w = _gpu(w, torch.float32, "weight")
+    Cout, Cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3, 3):
+        raise ValueError(f"conv_wino1d_weight3d: weight {tuple(w.shape)}")
+    blob = torch.empty(_lib.lib.ipdm_conv_wino1d_weight_bytes3d(Cout, Cin), dtype=torch.uint8, device=w.device)
+    call("ipdm_conv_wino1d_pack_weight3d", _ptr(w), _ptr(blob), Cout, Cin, _stream())
+    return PackedBx3(blob, Cout, Cin, 36, "hx2")
+
+
+def conv3d_wino1d(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, in_amax=None, want_amax=False, res_second=False):
+    """3x3x3 'same' convolution of x [B, Cin, D, H, W] on the 1-D Winograd kernel (same output options as conv3d)"""
+    x = _gpu(x, torch.float32, "x")
+    B, Cin, D, H, W = x.shape
+    if U.kk != 36 or U.Cin != Cin:
+        raise ValueError("conv3d_wino1d: weight blob does not match the input")
+    if res_second and (residual is None or act_out == ACT_NONE or not raw):
+        raise ValueError("conv3d_wino1d: res_second needs a residual and both outputs")
+    Cout = U.Cout
+    if residual is not None and tuple(residual.shape) != (B, Cout, D, H, W):
+        raise ValueError(f"conv3d_wino1d: residual {tuple(residual.shape)} != output {(B, Cout, D, H, W)}")
+    amax_t = None
+    if in_amax is not None:
+        amax_t = absmax_per_image(x) if in_amax is True else in_amax
+    want_amax = bool(want_amax) and B <= 65535 and os.environ.get("IPDM_AMAX_PRODUCE", "1") != "0"
+    want_act = act_out != ACT_NONE
+    slot_o = amax_slot(B, x.device) if want_amax and raw else None
+    slot_a = amax_slot(B, x.device) if want_amax and want_act else None
+    out = torch.empty((B, Cout, D, H, W), dtype=torch.float32, device=x.device) if raw else None
+    out_act = torch.empty((B, Cout, D, H, W), dtype=torch.float32, device=x.device) if want_act else None
+    if CONV_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    nb = max(1, (0x3fffffff - 1) // (Cin * D * H * W * 4))       # images per launch inside the buffer descriptor's reach
+    for b0 in range(0, B, nb):
+        b1 = min(B, b0 + nb)
+        ext = _conv_ext("hx2", None if amax_t is None else amax_t[b0:b1], x[b0:b1], False, False, 1.0, 0,
+                        None if slot_o is None else slot_o[b0:b1], None if slot_a is None else slot_a[b0:b1], res_second)
+        call("ipdm_conv3d_wino1d_f32", _ptr(x[b0:b1]), _ptr(U.blob), _ptr(bias), _ptr(None if residual is None else residual[b0:b1]),
+             _ptr(None if out is None else out[b0:b1]), _ptr(None if out_act is None else out_act[b0:b1]), act_out, b1 - b0, Cin,
+             Cout, D, H, W, ext, _stream())
+    if CONV_TRACE is not None:
+        e1.record()
+        CONV_TRACE.append(dict(B=B * D, Cin=Cin, Cout=Cout, H=H, W=W, k=3, dil=1, wino=True, bx3=True, fmt="hx2", wino1d=True,
+                               res=residual is not None, n_out=int(raw) + int(want_act), taps3d=27, e0=e0, e1=e1))
+    tag_amax(out, slot_o)
+    tag_amax(out_act, slot_a)
+    return (out, out_act) if want_act else out
+
+
+def wino1d_vol_pays(Cin, Cout, D, H, W, dilation=1):
+    """3x3x3 layers the 1-D Winograd kernel's volume form takes from the direct kernel (layer shape only)"""
+    return (WINO1D and WINO1D_VOL and CONV_IMPL == "hx2" and dilation == 1
+            and bool(_lib.lib.ipdm_conv3d_wino1d_supported(int(Cin), int(Cout), int(D), int(H), int(W))))
+
+
+WINO1D_VOL = os.environ.get("IPDM_WINO1D_VOL", "1") != "0"          # 0: config 4's 3x3x3 layers stay on the direct kernel (A/B)
 WINO1D = os.environ.get("IPDM_WINO1D", "1") != "0"          # 0: the 2-D Winograd kernel everywhere (A/B, fallback)
 WINO1D_STATS = os.environ.get("IPDM_WINO1D_STATS", "1") != "0"      # the launches with a statistics epilogue too (tuning)
 # InstanceNorm++ + ELU of the input inside the 1-D kernel's producer instead of the affine + activation pass: built, tested, and

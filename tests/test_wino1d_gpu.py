@@ -289,3 +289,32 @@ def test_residual_block_fused_norms_match_separate_passes(ops, monkeypatch):
                 ops.CONV_TRACE = None
         assert n >= 2
         assert (y1 - y0).abs().max() <= 5e-6 * y0.abs().max()
+
+
+@pytest.mark.parametrize("B,Cin,Cout,D,H,W", [(2, 32, 128, 5, 8, 12), (1, 64, 128, 4, 8, 24), (2, 32, 128, 3, 8, 8), (1, 32, 256, 6, 16, 12),
+                                              (1, 32, 128, 1, 8, 12), (2, 32, 128, 2, 10, 16), (1, 32, 128, 3, 8, 40)])
+def test_wino1d_volume_form(ops, B, Cin, Cout, D, H, W):
+    """3x3x3 'same' convolution on the 1-D Winograd kernel: depth taps as K chunks (zero planes outside the volume), two depth
+    slices per row block on planes of 12 pixels or less (odd depths: the last block holds one), every epilogue option of the
+    temporal network"""
+    gen = torch.Generator().manual_seed(61)
+    x = torch.randn(B, Cin, D, H, W, generator=gen).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (5 * Cin ** 0.5)).cuda()
+    b = torch.randn(Cout, generator=gen).cuda()
+    r = torch.randn(B, Cout, D, H, W, generator=gen).cuda()
+    assert ops._lib.lib.ipdm_conv3d_wino1d_supported(Cin, Cout, D, H, W) == 1
+    U = ops.conv_wino1d_weight3d(w)
+    with ops.amax_scope():
+        y, ya = ops.conv3d(x, U, b, residual=r, act_out=ops.ACT_ELU, in_amax=True, want_amax=True)
+        ref = F.conv3d(x.double(), w.double(), b.double(), padding=1) + r.double()
+        assert (y.double() - ref).abs().max() <= 1e-6 * ref.abs().max()
+        assert (ya.double() - F.elu(ref)).abs().max() <= 1e-6 * ref.abs().max()
+        assert torch.equal(ops.amax_value(ops.amax_of(y)), y.abs().amax(dim=(1, 2, 3, 4)))
+        assert torch.equal(ops.amax_value(ops.amax_of(ya)), ya.abs().amax(dim=(1, 2, 3, 4)))
+    y1 = ops.conv3d(x, U, b, residual=r, in_amax=True)                    # one output: another instantiation, the same bits
+    assert torch.equal(y1, y)
+    path, xs = ops.conv3d(x, U, b, residual=r, act_out=ops.ACT_COPY, res_second=True)
+    plain = ops.conv3d(x, U, b)
+    assert torch.equal(path, plain) and torch.equal(xs, plain + r)
+    yd = ops.conv3d(x, ops.conv_bx3_weight(w, fmt="hx2"), b, residual=r)             # the direct kernel it stands in for
+    assert (y1 - yd).abs().max() <= 1e-6 * yd.abs().max()
