@@ -262,6 +262,11 @@ int ipdm_groupnorm_coef_f32(const float* x, const float* weight, const float* bi
  * `torch.cat([h, hs.pop()], dim=1)`, models/ncsnpp.py:351): coefficients [B][C1+C2][3] from the two tensors' planes, then one
  * pass that writes the normalised, activated, concatenated tensor.  IPDM_EUNSUPPORTED outside the single-read plane kernels
  * (HW % 4 != 0, HW > 65536, more than 65535 planes): concatenate and use the one-tensor calls. */
+/* ... from the statistics partials of the convolution(s) that produced the tensor(s) (the _stats_f32 convolution calls: [B][C][P][3]
+ * = count, mean, sum of squared deviations per pixel block): the tensor is not read.  part2 / C2 (may be NULL / 0): the channels
+ * >= C1 of torch.cat([x1, x2], dim=1). */
+int ipdm_groupnorm_coef_partials_f32(const float* part1, int C1, const float* part2, int C2, int P, const float* weight,
+                                     const float* bias, float* coef /* [B][C1+C2][3] */, int B, int G, float eps, void* stream);
 int ipdm_groupnorm_coef_cat_f32(const float* x1, int C1, const float* x2, int C2, const float* weight, const float* bias,
                                 float* coef, int B, int HW, int G, float eps, float* plane_amax /* may be NULL; [B][C1+C2] */,
                                 void* stream);

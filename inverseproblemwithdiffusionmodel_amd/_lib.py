@@ -63,6 +63,7 @@ SIGNATURES = {
     "ipdm_conv3x3_thin_f32": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "ipdm_trilinear_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "ipdm_groupnorm_coef_f32": [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P, P],
+    "ipdm_groupnorm_coef_partials_f32": [P, c_int, P, c_int, c_int, P, P, P, c_int, c_int, c_float, P],
     "ipdm_groupnorm_coef_cat_f32": [P, c_int, P, c_int, P, P, P, c_int, c_int, c_int, c_float, P, P],
     "ipdm_affine_act_cat_f32": [P, c_int, P, c_int, P, P, c_int, c_int, c_int, P],
     "ipdm_linear_f32": [P, P, P, P, c_int, c_int, c_int, c_int, P],

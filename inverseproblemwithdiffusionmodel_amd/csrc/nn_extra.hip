@@ -331,6 +331,81 @@ extern "C" int ipdm_adam_ascent_f32(float* x, const float* g, float* m, float* v
   return ipdm_launch_status();
 }
 
+// GroupNorm coefficients from the producing convolutions' statistics partials ([B][C][P][3] = count, mean, sum of squared deviations
+// per pixel block; conv_wino1d.hip / conv_wino_bx3.hip STATS epilogues) -- the tensor is not read at all.  One 256-thread workgroup
+// per (image, group): thread t merges the group's partials t, t+256, ... in index order (Chan et al., float64), a butterfly merges
+// the lanes of a wave and every thread then merges the four waves' triples in wave order (symmetric updates: a fixed tree, whatever
+// the batch).  (part2, C2): the group's channels >= C1 come from a second tensor's
+// partials -- GroupNorm of torch.cat([x1, x2], dim=1) without the concatenation.
+__global__ __launch_bounds__(256) void gn_from_partials_kernel(const float* __restrict__ part1, int C1, const float* __restrict__ part2,
+                                                              int C2, int P, const float* __restrict__ weight,
+                                                              const float* __restrict__ bias, float* __restrict__ coef, int G,
+                                                              float eps) {
+  const int C = C1 + C2, cpg = C / G;
+  const int b = blockIdx.x / G, g = blockIdx.x % G;
+  const int lane = threadIdx.x;
+  __shared__ double red[4][3];
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int i = lane; i < cpg * P; i += 256) {
+    const int c = g * cpg + i / P, q = i % P;
+    const float* pp = c < C1 ? part1 + (((size_t)b * C1 + c) * P + q) * 3 : part2 + (((size_t)b * C2 + (c - C1)) * P + q) * 3;
+    const double nb = pp[0], mb = pp[1], qb = pp[2];
+    if (nb > 0.0) {
+      const double nn = n + nb, d = mb - mean;
+      mean += d * (nb / nn);
+      m2 += qb + d * d * (n * nb / nn);
+      n = nn;
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const double nb = __shfl_xor(n, m, 64), mb = __shfl_xor(mean, m, 64), qb = __shfl_xor(m2, m, 64);
+    const double nn = n + nb;
+    if (nn > 0.0) {
+      const double d = mb - mean;
+      const double new_mean = (n * mean + nb * mb) / nn;
+      m2 = (m2 + qb) + d * d * (n * nb / nn);
+      mean = new_mean;
+      n = nn;
+    }
+  }
+  if ((lane & 63) == 0) {
+    red[lane >> 6][0] = n; red[lane >> 6][1] = mean; red[lane >> 6][2] = m2;
+  }
+  __syncthreads();
+  n = red[0][0]; mean = red[0][1]; m2 = red[0][2];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const double nb = red[w][0], mb = red[w][1], qb = red[w][2];
+    const double nn = n + nb;
+    if (nn > 0.0) {
+      const double d = mb - mean;
+      const double new_mean = (n * mean + nb * mb) / nn;
+      m2 = (m2 + qb) + d * d * (n * nb / nn);
+      mean = new_mean;
+      n = nn;
+    }
+  }
+  const float rstd = 1.0f / sqrtf((float)(n > 0.0 ? m2 / n : 0.0) + eps);
+  for (int c = lane; c < cpg; c += 256) {
+    const int ch = g * cpg + c;
+    float* o = coef + ((size_t)b * C + ch) * 3;
+    o[0] = (float)mean;
+    o[1] = (weight ? weight[ch] : 1.f) * rstd;
+    o[2] = bias ? bias[ch] : 0.f;
+  }
+}
+
+extern "C" int ipdm_groupnorm_coef_partials_f32(const float* part1, int C1, const float* part2, int C2, int P, const float* weight,
+                                                const float* bias, float* coef, int B, int G, float eps, void* stream) {
+  IPDM_REQUIRE(B >= 0 && C1 > 0 && C2 >= 0 && P > 0 && G > 0 && (C1 + C2) % G == 0);
+  if (B == 0) return IPDM_OK;
+  IPDM_REQUIRE(part1 && coef && (C2 == 0 || part2));
+  hipLaunchKernelGGL(gn_from_partials_kernel, dim3(B * G), dim3(256), 0, ipdm_stream(stream), part1, C1, part2, C2, P, weight, bias,
+                     coef, G, eps);
+  return ipdm_launch_status();
+}
+
 extern "C" int ipdm_groupnorm_coef_f32(const float* x, const float* weight, const float* bias, float* coef, int B, int C,
                                        int HW, int G, float eps, float* plane_amax, void* stream) {
   IPDM_REQUIRE(B >= 0 && C > 0 && HW > 0 && G > 0 && C % G == 0);

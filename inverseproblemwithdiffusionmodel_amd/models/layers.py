@@ -3,6 +3,8 @@ get_act :29-41, variance_scaling/default_init :54-91, ddpm_conv1x1/3x3 :100-125,
 NIN :547-556) on the libipdm.so kernels."""
 import math
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -37,6 +39,10 @@ def default_init(scale=1.):
     return variance_scaling(scale, 'fan_avg', 'uniform')
 
 
+# GroupNorm statistics from the producing convolution's epilogue partials (IPDM_GN_PARTIALS=0: always from a pass over the tensor)
+GN_FROM_PARTIALS = os.environ.get("IPDM_GN_PARTIALS", "1") != "0"
+
+
 class Conv(ops.PackedWeightMixin, nn.Module):
     """stride-1 'same' convolution with nn.Conv2d's parameter names (weight [Cout,Cin,k,k], bias)"""
 
@@ -59,11 +65,14 @@ class Conv(ops.PackedWeightMixin, nn.Module):
     def packed_wino1d(self):
         return self._cache.get(self.weight, "wino1d", ops.conv_wino1d_weight)
 
-    def forward(self, x, residual=None, bounded=False, bias_rows=None, out_scale=1.0, in_amax=None, feeds_conv=False):
+    def forward(self, x, residual=None, bounded=False, bias_rows=None, out_scale=1.0, in_amax=None, feeds_conv=False,
+                want_stats=False):
         """bounded: x is act(GroupNorm(.)) (possibly FIR-resampled) -- |x| <= |gamma| sqrt(group size) + |beta|, inside the
         f16x2 family's static range; otherwise (raw skip / pyramid / input streams) the convolution runs with the dynamic
         range: the per-image maxima ride on the tensor from its producer (ops.in_amax_for: a convolution epilogue, a FIR
         resampler passing its input's bound on) or are measured once and attached.
+        want_stats: a GroupNorm reads this layer's result next: where the convolution kernel has a statistics epilogue its partials
+        ride on the result (ops.stats_partials_of) and that GroupNorm does not read the tensor for its statistics.
         feeds_conv: a convolution reads this layer's RESULT raw (a block's output: the next shortcut / the skip connection):
         the epilogue accumulates its maxima.
         bias_rows [B, Cout]: replaces the bias by one row per image (the caller has added self.bias into it);
@@ -84,7 +93,8 @@ class Conv(ops.PackedWeightMixin, nn.Module):
             one_d = (impl == "hx2" and x.data_ptr() % 16 == 0
                      and ops.wino1d_pays(self.in_planes, self.out_planes, x.shape[2], x.shape[3], self.dilation))
             return ops.conv2d_wino_bx3(x, self.packed_wino1d() if one_d else self.packed_wino(), bias, residual,
-                                       dilation=self.dilation, in_amax=amax, out_scale=out_scale, want_amax=produce)
+                                       dilation=self.dilation, in_amax=amax, out_scale=out_scale, want_amax=produce,
+                                       want_stats=want_stats and GN_FROM_PARTIALS)
         return ops.conv2d(x, self.packed(), bias, residual=residual, dilation=self.dilation, in_amax=amax, out_scale=out_scale,
                           want_amax=produce)
 

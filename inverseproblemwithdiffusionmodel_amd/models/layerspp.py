@@ -183,7 +183,8 @@ class ResnetBlockDDPMpp(_TembBiasOwner, nn.Module):
         code = self.act.code
         fold = self.Conv_0.epilogue_folds()
         if temb is not None and fold:
-            h = self.Conv_0(self.GroupNorm_0(x, code), bounded=True, bias_rows=self._temb_bias.rows(self.Dense_0, self.Conv_0, temb, code))
+            h = self.Conv_0(self.GroupNorm_0(x, code), bounded=True, want_stats=True,     # GroupNorm_1 reads the result next
+                            bias_rows=self._temb_bias.rows(self.Dense_0, self.Conv_0, temb, code))
         else:
             h = self.Conv_0(self.GroupNorm_0(x, code), bounded=True)
             if temb is not None:
@@ -194,7 +195,7 @@ class ResnetBlockDDPMpp(_TembBiasOwner, nn.Module):
             x = self.Conv_2(x) if self.conv_shortcut else self.NIN_0(x)
         if fold:                                                   # (x + Conv_1(.)) [/ sqrt 2] in Conv_1's epilogue
             return self.Conv_1(self.GroupNorm_1(h, code), residual=x, bounded=True,
-                               out_scale=INV_SQRT2 if self.skip_rescale else 1.0, feeds_conv=True)
+                               out_scale=INV_SQRT2 if self.skip_rescale else 1.0, feeds_conv=True, want_stats=True)
         h = self.Conv_1(self.GroupNorm_1(h, code), bounded=True)
         return _skip(x, h, self.skip_rescale)
 
@@ -257,7 +258,8 @@ class ResnetBlockBigGANpp(_TembBiasOwner, nn.Module):
         fold = self.Conv_0.epilogue_folds()
         if temb is not None and fold:
             # h += Dense_0(act(temb))[:, :, None, None]: one bias row per image in Conv_0's epilogue
-            h = self.Conv_0(h, bounded=True, bias_rows=self._temb_bias.rows(self.Dense_0, self.Conv_0, temb, code))
+            h = self.Conv_0(h, bounded=True, want_stats=True,    # GroupNorm_1 reads the result next
+                            bias_rows=self._temb_bias.rows(self.Dense_0, self.Conv_0, temb, code))
         else:
             h = self.Conv_0(h, bounded=True)                     # act(GroupNorm(x)), FIR-resampled: bounded
             if temb is not None:
@@ -271,6 +273,7 @@ class ResnetBlockBigGANpp(_TembBiasOwner, nn.Module):
             x = torch.cat(parts, dim=1)
         if fold:                                                   # (x + Conv_1(h)) [/ sqrt 2] in Conv_1's epilogue
             return self.Conv_1(h, residual=x, bounded=True, out_scale=INV_SQRT2 if self.skip_rescale else 1.0,
-                               feeds_conv=True)                    # a block's output: shortcuts / skip connections read it raw
+                               feeds_conv=True, want_stats=True)   # a block's output: shortcuts / skip connections read it raw,
+                                                                   # the next block's GroupNorm_0 takes its statistics
         h = self.Conv_1(h, bounded=True)
         return _skip(x, h, self.skip_rescale)

@@ -693,12 +693,30 @@ def trilinear(x, size, out=None, accumulate=False, act=ACT_NONE, want_amax=False
 
 
 # ---- NCSN++ / predictor-corrector extras --------------------------------------------------------
+def stats_partials_of(x):
+    """the statistics partials [B, C, P, 3] the producing convolution's epilogue hung on x (conv2d_wino_bx3(want_stats=True)), or
+    None -- also None when x was written since (the tag is its (version, data_ptr))"""
+    part = getattr(x, "_ipdm_partials", None)
+    if part is None or not USE_STATS_EPILOGUE:
+        return None
+    part, tag = part
+    if tag != (x._version, x.data_ptr()) or tuple(part.shape[:2]) != tuple(x.shape[:2]):
+        return None
+    return part
+
+
 def groupnorm_coef(x, weight, bias, groups, eps=1e-6, want_amax=False):
     """-> coef [B, C, 3]; want_amax: -> (coef, per-image max |x| [B]) -- the maxima come out of the statistics pass (planes in
-    registers) plus one tiny reduction; where that pass is not the single-read kernel the input is measured separately"""
+    registers) plus one tiny reduction; where that pass is not the single-read kernel the input is measured separately.
+    Where x carries its producer's statistics partials (stats_partials_of) the coefficients come from those: x is not read."""
     x = _gpu(x, torch.float32, "x")
     B, C, H, W = x.shape
     coef = torch.empty((B, C, 3), dtype=torch.float32, device=x.device)
+    part = None if want_amax else stats_partials_of(x)
+    if part is not None:
+        call("ipdm_groupnorm_coef_partials_f32", _ptr(part), C, _ptr(None), 0, int(part.shape[2]), _ptr(weight), _ptr(bias),
+             _ptr(coef), B, groups, float(eps), _stream())
+        return coef
     if want_amax:
         planes = torch.empty((B, C), dtype=torch.float32, device=x.device)
         try:
@@ -723,6 +741,15 @@ def groupnorm_act_cat(x1, x2, weight, bias, groups, eps=1e-6, act=ACT_NONE, want
     coef = torch.empty((B, C1 + C2, 3), dtype=torch.float32, device=x1.device)
     out = torch.empty((B, C1 + C2, H, W), dtype=torch.float32, device=x1.device)
     planes = torch.empty((B, C1 + C2), dtype=torch.float32, device=x1.device) if want_amax else None
+    p1, p2 = (None, None) if want_amax else (stats_partials_of(x1), stats_partials_of(x2))
+    if p1 is not None and p2 is not None and p1.shape[2] == p2.shape[2]:       # both producers left their statistics: no read
+        try:
+            call("ipdm_groupnorm_coef_partials_f32", _ptr(p1), C1, _ptr(p2), C2, int(p1.shape[2]), _ptr(weight), _ptr(bias),
+                 _ptr(coef), B, groups, float(eps), _stream())
+            call("ipdm_affine_act_cat_f32", _ptr(x1), C1, _ptr(x2), C2, _ptr(coef), _ptr(out), B, H * W, act, _stream())
+            return out
+        except _lib.IpdmUnsupported:
+            pass
     try:
         call("ipdm_groupnorm_coef_cat_f32", _ptr(x1), C1, _ptr(x2), C2, _ptr(weight), _ptr(bias), _ptr(coef), B, H * W, groups,
              float(eps), _ptr(planes), _stream())

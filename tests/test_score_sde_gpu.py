@@ -341,3 +341,41 @@ def test_ncsnpp_ddpm_blocks_with_resampling_conv(golden):
         ref_dn = F.conv2d(F.pad(h.double(), (0, 1, 0, 1)), dn.Conv_0.weight.double(), dn.Conv_0.bias.double(), stride=2)
         assert (up(h).double() - ref_up).abs().max() <= 1e-5 * ref_up.abs().max()
         assert (dn(h).double() - ref_dn).abs().max() <= 1e-5 * ref_dn.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C1,C2,H,W,G", [(128, 0, 64, 64, 32), (256, 128, 32, 64, 32), (128, 128, 40, 36, 16)])
+def test_groupnorm_from_convolution_partials(C1, C2, H, W, G):
+    """GroupNorm coefficients from the producing convolutions' statistics partials (no pass over the tensor) equal the ones from
+    the tensor -- single tensors and the two-tensor (concatenation-free) form; a tensor written since falls back to the pass"""
+    from inverseproblemwithdiffusionmodel_amd import ops
+    if ops.CONV_IMPL != "hx2":
+        pytest.skip("the statistics epilogue used here belongs to the f16x2 1-D Winograd kernel")
+    gen = torch.Generator().manual_seed(71)
+    B = 2
+
+    def produced(C):
+        x = torch.randn(B, 64, H, W, generator=gen).cuda()
+        w = (torch.randn(C, 64, 3, 3, generator=gen) * 0.1).cuda()
+        b = (torch.randn(C, generator=gen) * 2).cuda()
+        y = ops.conv2d_wino_bx3(x, ops.conv_wino1d_weight(w), b, want_stats=True)
+        assert ops.stats_partials_of(y) is not None
+        return y
+    y1 = produced(C1)
+    weight = torch.randn(C1 + C2, generator=gen).cuda()
+    bias = torch.randn(C1 + C2, generator=gen).cuda()
+    if C2 == 0:
+        c_part = ops.groupnorm_coef(y1, weight, bias, G)
+        ref = torch.nn.functional.group_norm(y1.double(), G, weight.double(), bias.double(), eps=1e-6)
+        got = ops.affine_act(y1, c_part)
+        assert (got.double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+        y1.mul_(1.5)                                                       # written in place: the partials are stale
+        assert ops.stats_partials_of(y1) is None
+        ref2 = torch.nn.functional.group_norm(y1.double(), G, weight.double(), bias.double(), eps=1e-6)
+        assert (ops.affine_act(y1, ops.groupnorm_coef(y1, weight, bias, G)).double() - ref2).abs().max() <= 2e-5 * ref2.abs().max()
+    else:
+        y2 = produced(C2)
+        got = ops.groupnorm_act_cat(y1, y2, weight, bias, G, act=ops.ACT_SWISH)
+        cat = torch.cat([y1, y2], dim=1).double()
+        ref = torch.nn.functional.silu(torch.nn.functional.group_norm(cat, G, weight.double(), bias.double(), eps=1e-6))
+        assert (got.double() - ref).abs().max() <= 2e-5 * ref.abs().max()
