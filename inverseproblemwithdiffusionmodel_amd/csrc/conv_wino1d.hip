@@ -602,8 +602,13 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) {
             const unsigned ob = boff(c, nb, half * 2 + kk);
-#ifdef IPDM_W1D_NO_NT
+#if defined(IPDM_W1D_NO_NT)
             if constexpr (W_OUT) *reinterpret_cast<vecv*>(out_b + ob) = ov[kk];
+#elif defined(IPDM_W1D_NT_BIG)
+            if constexpr (W_OUT) {                                  // (experiment: streaming stores only for tensors beyond the MALL)
+              if ((size_t)a.B * a.Cout * HW > (size_t)IPDM_W1D_NT_BIG * 262144) __builtin_nontemporal_store(ov[kk], reinterpret_cast<vecv*>(out_b + ob));
+              else *reinterpret_cast<vecv*>(out_b + ob) = ov[kk];
+            }
 #else
             if constexpr (W_OUT) __builtin_nontemporal_store(ov[kk], reinterpret_cast<vecv*>(out_b + ob));
 #endif
