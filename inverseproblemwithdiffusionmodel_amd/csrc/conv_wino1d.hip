@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
   // phase groups (tuning, IPDM_W1D_STAGGER): group slot % 4 starts g * stagger cycles late, so that the workgroups' epilogues -- all
   // 256 hit HBM in the same microseconds otherwise -- are spread over the pass
   if (a.ksplit > 1) {
-    const int g = slot & 3;
+    const int g = slot & (a.pool2 >> 8);                        // (launcher: group mask in the spare bits of pool2)
     for (int i = 0; i < g * (a.ksplit - 1); ++i) __builtin_amdgcn_s_sleep(8);          // ~8 x 64 cycles each
   }
 
@@ -684,17 +684,26 @@ bool wino1d_ok(const ConvArgs& a) {
 }
 
 int conv_wino1d_launch(ConvArgs a, hipStream_t s) {
-  static int stagger = -1;                       // IPDM_W1D_STAGGER=<cycles>: start delay per phase group (tuning)
+  // IPDM_W1D_STAGGER=<cycles>[:<groups 2|4|8>[:<min passes per workgroup>]]: start delay per phase group
+  static int stagger = -1, st_groups = 4, st_minpass = 0;
   if (stagger < 0) {
     const char* e = getenv("IPDM_W1D_STAGGER");
-    stagger = e ? atoi(e) / 512 : 0;
+    stagger = 0;
+    if (e) {
+      int c = 0, g = 4, m = 0;
+      const int n = sscanf(e, "%d:%d:%d", &c, &g, &m);
+      if (n >= 1) stagger = c / 512;
+      if (n >= 2 && (g == 2 || g == 4 || g == 8)) st_groups = g;
+      if (n >= 3) st_minpass = m;
+    }
   }
-  a.ksplit = stagger > 0 ? stagger + 1 : 1;
   a.tiles_x = (a.W + 2 * Y_TX - 1) / (2 * Y_TX);
   a.tiles_y = (a.H + Y_ROWS - 1) / Y_ROWS;
   a.co_tiles = a.Cout / Y_CO;
   const int64_t nblk = (int64_t)a.B * a.tiles_x * a.tiles_y * a.co_tiles;
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
+  a.ksplit = stagger > 0 && nblk >= (int64_t)st_minpass * 256 ? stagger + 1 : 1;
+  a.pool2 |= (st_groups - 1) << 8;
   static bool attr_set = false;
   if (!attr_set) {
 #define W1D_K(O, S_, P_) reinterpret_cast<const void*>(conv_wino1d_kernel<O, S_, P_, false>), reinterpret_cast<const void*>(conv_wino1d_kernel<O, S_, P_, true>)
@@ -718,7 +727,7 @@ int conv_wino1d_launch(ConvArgs a, hipStream_t s) {
     if (a.coef) hipLaunchKernelGGL((conv_wino1d_kernel<O, S_, P_, true>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk); \
     else hipLaunchKernelGGL((conv_wino1d_kernel<O, S_, P_, false>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);      \
   } while (0)
-  if (a.pool2) {
+  if (a.pool2 & 1) {
     if (a.stats) { if (outs == 3) W1D_LAUNCH(3, true, true); else W1D_LAUNCH(1, true, true); }
     else if (outs == 3) W1D_LAUNCH(3, false, true);
     else if (outs == 1) W1D_LAUNCH(1, false, true);
