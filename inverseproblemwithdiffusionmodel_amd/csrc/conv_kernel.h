@@ -142,6 +142,7 @@ struct ConvArgs {
   float* amax_act = nullptr; //   |stored value| per image, one atomic max per wave (ipdm_common.h) -- the NEXT convolution's in_amax
   int hx = 0;                // conv_bx3 / conv_wino_bx3: 1 = the weights are an f16x2 blob (two fp16 pieces + per-channel inverse
                              //   scales), run the three-MFMA fp16 instantiation
+  int phase_step = 0, phase_mask = 0;   // conv_wino1d (tuning, IPDM_W1D_STAGGER): workgroup slot & phase_mask starts g * phase_step x 512 cycles late
   float* stats = nullptr;    // conv_wino_bx3 wide kernel (16 x 4 tile block, 16-byte DMA) only: per-plane statistics of
                              //   the RESULT as deterministic partials [B][Cout][P][3] = (count, mean, sum of squared
                              //   deviations) per (tile block, tile group), P = 2 * tiles_y * tiles_x -- what the following

@@ -136,9 +136,9 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
   if (tile >= t_end) return;
   // phase groups (tuning, IPDM_W1D_STAGGER): group slot % 4 starts g * stagger cycles late, so that the workgroups' epilogues -- all
   // 256 hit HBM in the same microseconds otherwise -- are spread over the pass
-  if (a.ksplit > 1) {
-    const int g = slot & (a.pool2 >> 8);                        // (launcher: group mask in the spare bits of pool2)
-    for (int i = 0; i < g * (a.ksplit - 1); ++i) __builtin_amdgcn_s_sleep(8);          // ~8 x 64 cycles each
+  if (a.phase_step > 0) {
+    const int g = slot & a.phase_mask;
+    for (int i = 0; i < g * a.phase_step; ++i) __builtin_amdgcn_s_sleep(8);             // ~8 x 64 cycles each
   }
 
   struct Geo { int b, y0, x0, cob, z; };
@@ -312,14 +312,6 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
       vs[(x * 2 + 1) * 128] = lp;
     }
   };
-  auto stage_all = [&](unsigned* st) {
-    read_items();
-    static_for<3>([&](auto itc) {
-      float va[4], vb[4];
-      xform_item(itc, va, vb);
-      store_item(st, itc, va, vb, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
-    });
-  };
 
   // ---- consumer operands ----
   const uint4* wq = reinterpret_cast<const uint4*>(a.wt);
@@ -365,12 +357,18 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
   hx_scales_of(cur_g.b, hx_in, hx_out);
   set_dma_geo(cur_g);
   issue_dma(0);
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
+  __builtin_amdgcn_s_waitcnt(0);                               // (the raw blocks are wave-private: no barrier before reading them)
   set_fin(cur_g.b, 0, cur_g.y0, cur_g.x0);
-  stage_all(ldsw);
-  __syncthreads();
-  issue_dma(1);
+  read_items();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0): chunk 0's rows are in registers
+  issue_dma(1);                                                // ... so chunk 1 lands while chunk 0 is transformed and stored
+  __builtin_amdgcn_sched_barrier(0);
+  static_for<3>([&](auto itc) {
+    float va[4], vb[4];
+    xform_item(itc, va, vb);
+    store_item(ldsw, itc, va, vb, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+  });
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
 
@@ -702,8 +700,8 @@ int conv_wino1d_launch(ConvArgs a, hipStream_t s) {
   a.co_tiles = a.Cout / Y_CO;
   const int64_t nblk = (int64_t)a.B * a.tiles_x * a.tiles_y * a.co_tiles;
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
-  a.ksplit = stagger > 0 && nblk >= (int64_t)st_minpass * 256 ? stagger + 1 : 1;
-  a.pool2 |= (st_groups - 1) << 8;
+  a.phase_step = stagger > 0 && nblk >= (int64_t)st_minpass * 256 ? stagger : 0;
+  a.phase_mask = st_groups - 1;
   static bool attr_set = false;
   if (!attr_set) {
 #define W1D_K(O, S_, P_) reinterpret_cast<const void*>(conv_wino1d_kernel<O, S_, P_, false>), reinterpret_cast<const void*>(conv_wino1d_kernel<O, S_, P_, true>)
@@ -727,7 +725,7 @@ int conv_wino1d_launch(ConvArgs a, hipStream_t s) {
     if (a.coef) hipLaunchKernelGGL((conv_wino1d_kernel<O, S_, P_, true>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk); \
     else hipLaunchKernelGGL((conv_wino1d_kernel<O, S_, P_, false>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);      \
   } while (0)
-  if (a.pool2 & 1) {
+  if (a.pool2) {
     if (a.stats) { if (outs == 3) W1D_LAUNCH(3, true, true); else W1D_LAUNCH(1, true, true); }
     else if (outs == 3) W1D_LAUNCH(3, false, true);
     else if (outs == 1) W1D_LAUNCH(1, false, true);
@@ -827,7 +825,6 @@ int conv_wino1d_vol_launch(ConvArgs a, hipStream_t s) {
   a.tiles_x = pack ? 1 : (a.W + 2 * Y_TX - 1) / (2 * Y_TX);
   a.tiles_y = (a.H + Y_ROWS - 1) / Y_ROWS;
   a.co_tiles = a.Cout / Y_CO;
-  a.ksplit = 1;
   const int64_t nblk = (int64_t)a.B * (pack ? (a.D + 1) / 2 : a.D) * a.tiles_x * a.tiles_y * a.co_tiles;
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
   static bool attr_set = false;
