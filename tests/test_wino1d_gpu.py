@@ -318,3 +318,23 @@ def test_wino1d_volume_form(ops, B, Cin, Cout, D, H, W):
     assert torch.equal(path, plain) and torch.equal(xs, plain + r)
     yd = ops.conv3d(x, ops.conv_bx3_weight(w, fmt="hx2"), b, residual=r)             # the direct kernel it stands in for
     assert (y1 - yd).abs().max() <= 1e-6 * yd.abs().max()
+
+
+def test_wino1d_linearity_and_shift_at_full_size(ops):
+    """size-independent properties at the headline layer's full size (B = 28, 128 -> 128 @128^2, where no float64 reference
+    finishes in seconds): linearity conv(a x1 + b x2) = a conv(x1) + b conv(x2), and equivariance under a shift by one 8 x 32 pixel
+    block (interior pixels: another workgroup, another position in its tile list, the same sum)"""
+    gen = torch.Generator(device="cuda").manual_seed(81)
+    B, C, H, W = 28, 128, 128, 128
+    x1 = torch.randn(B, C, H, W, device="cuda", generator=gen)
+    x2 = torch.randn(B, C, H, W, device="cuda", generator=gen)
+    w = torch.randn(C, C, 3, 3, device="cuda", generator=gen) / (3 * C ** 0.5)
+    U = ops.conv_wino1d_weight(w)
+    y1, y2 = ops.conv2d_wino_bx3(x1, U), ops.conv2d_wino_bx3(x2, U)
+    y12 = ops.conv2d_wino_bx3(0.5 * x1 - 2.0 * x2, U)                  # (power-of-two coefficients: the combination is exact)
+    ref = 0.5 * y1 - 2.0 * y2
+    assert (y12 - ref).abs().max() <= 2e-6 * ref.abs().max()
+    xs = torch.roll(x1, shifts=(8, 32), dims=(2, 3))
+    ys = ops.conv2d_wino_bx3(xs, U)
+    assert torch.equal(ys[:, :, 10:-2, 34:-2], torch.roll(y1, shifts=(8, 32), dims=(2, 3))[:, :, 10:-2, 34:-2])
+    assert torch.isfinite(y12).all()
