@@ -615,10 +615,16 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_kernel(ConvArgs a) {
 // 26 16-byte LDS-DMA pieces per chunk whose out-of-image quads the range check zeroes; a thread gathers its 4 x 4 patch
 // from there (16 LDS reads) instead of 16 scattered 4-byte global loads per patch -- the address path was what held the
 // register-staged kernel at 12.7 k cycles per chunk on dilation-2 layers.
-template <bool HX, int TX, int TY, bool CO_MAJOR, bool DMA4, bool POOL = false, bool STATS = false, bool KSP = false, bool POLY = false>
+// CO32: 32 output channels per workgroup (one channel tile per wave instead of two: half the accumulators) -- for 16-pixel layers with
+// fewer than 512 output channels, whose (image, 64-channel tile) pairs fill under half of the chip: twice the workgroups, the whole K
+// loop in each, instead of two K halves + a reduction launch
+template <bool HX, int TX, int TY, bool CO_MAJOR, bool DMA4, bool POOL = false, bool STATS = false, bool KSP = false, bool POLY = false,
+          bool CO32 = false>
 __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int total_tiles) {
   constexpr int NPC = HX ? 2 : 3;                            // operand pieces; FRAG: 16-byte units per (chunk, channel tile)
   constexpr int FRAG = 64 * NPC;
+  constexpr int NC = CO32 ? 1 : 2;                           // 32-channel tiles per workgroup
+  static_assert(!CO32 || (HX && TX == 8 && TY == 8 && DMA4 && !POOL && !STATS && !KSP && !POLY), "CO32: the plain 8 x 8 form");
   static_assert(!POLY || (TX == 8 && TY == 8 && DMA4 && !POOL && !STATS && !KSP), "POLY: the 8 x 8 form, plain epilogue");
   constexpr int PPW = 24, PPH = 17;                           // POLY: padded row pitch / rows per channel
   constexpr int QC = POLY ? PPW / 4 : TX / 2 + 2, RC4 = 4 * QC;   // quads / floats per raw row (x0-4 .. x0+2TX+3)
@@ -901,10 +907,10 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
 
   const uint4* wq = reinterpret_cast<const uint4*>(a.wt);
   const size_t pos_stride = (size_t)n_cc * n_ct * FRAG;
-  auto load_A = [&](uint4 (&fr)[2][NPC], int p, int cc, int co_tile) {
-    const uint4* base = wq + (size_t)p * pos_stride + ((size_t)cc * n_ct + co_tile * 2) * FRAG + lane;
+  auto load_A = [&](uint4 (&fr)[NC][NPC], int p, int cc, int co_tile) {
+    const uint4* base = wq + (size_t)p * pos_stride + ((size_t)cc * n_ct + co_tile * NC) * FRAG + lane;
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int s = 0; s < NPC; ++s) fr[c][s] = base[c * FRAG + s * 64];
   };
@@ -921,18 +927,18 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       fr[s] = make_uint4(bp[s * 8 * X_TILES], bp[(s * 8 + 1) * X_TILES], bp[(s * 8 + 2) * X_TILES], bp[(s * 8 + 3) * X_TILES]);
   };
 
-  f32x16 acc[2][2][2];
+  f32x16 acc[2][NC][2];
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4 * NC; ++i)
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) acc[i >> 2][(i >> 1) & 1][i & 1][rr] = 0.f;
+      for (int rr = 0; rr < 16; ++rr) acc[i / (2 * NC)][(i >> 1) % NC][i & 1][rr] = 0.f;
   };
   zero_acc();
 
   // ---- prologue of the first tile ----
   Geo cur_g = geo_of(tile);
-  uint4 afr[2][2][NPC];
+  uint4 afr[2][NC][NPC];
   load_A(afr[0], p0, cur_g.c0, cur_g.co_tile);
   if constexpr (WPRIV) load_A(afr[1], p0 + 1, cur_g.c0, cur_g.co_tile);
   hx_scales_of(cur_g.b, hx_in, hx_out);
@@ -1029,7 +1035,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
           if constexpr (st == 3) store_pair(nxt, va, vb, std::integral_constant<int, 8>{}, std::integral_constant<int, 16>{});
           const f16x8 bh = __builtin_bit_cast(f16x8, bsh[st & 1][0]), bl = __builtin_bit_cast(f16x8, bsh[st & 1][1]);
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
+          for (int c = 0; c < NC; ++c) {
             f32x16 v = acc[pi][c][tg];
             v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][1]), bh, v, 0, 0, 0);
             v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][0]), bl, v, 0, 0, 0);
@@ -1081,7 +1087,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
           if constexpr (st == 3) store_pair(nxt, va, vb, std::integral_constant<int, 8>{}, std::integral_constant<int, 16>{});
           const f16x8 bh = __builtin_bit_cast(f16x8, bsh[st & 1][0]), bl = __builtin_bit_cast(f16x8, bsh[st & 1][1]);
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
+          for (int c = 0; c < NC; ++c) {
             f32x16 v = acc[pi][c][tg];
             v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][1]), bh, v, 0, 0, 0);
             v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][0]), bl, v, 0, 0, 0);
@@ -1128,7 +1134,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
         if constexpr (HX) {
           const f16x8 bh = __builtin_bit_cast(f16x8, bsh[st & 1][0]), bl = __builtin_bit_cast(f16x8, bsh[st & 1][1]);
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
+          for (int c = 0; c < NC; ++c) {
             f32x16 v = acc[pi][c][tg];
             v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][1]), bh, v, 0, 0, 0);
             v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[pi][c][0]), bl, v, 0, 0, 0);
@@ -1149,7 +1155,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
         if constexpr (st < 3) split3(raw, bs[(st + 1) & 1][0], bs[(st + 1) & 1][1], bs[(st + 1) & 1][2]);
         const bf16x8 bh = bs[st & 1][0], bm = bs[st & 1][1], bl = bs[st & 1][2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
           f32x16 v = acc[pi][c][tg];
           v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[pi][c][2]), bh, v, 0, 0, 0);
           v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[pi][c][0]), bl, v, 0, 0, 0);
@@ -1194,7 +1200,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     float* ms = lds + ((g - 1) & 1) * X_V_ELEMS;              // M[pos 16][co 32][tile 32]
     IPDM_TE(0);
     const int etile = tid & 31, ecg = tid >> 5;               // this thread: tile, channels 2*ecg, 2*ecg+1 of the 32
-    const int co0 = cur_g.co_tile * X_CO;
+    const int co0 = cur_g.co_tile * (CO32 ? 32 : X_CO);
     // bias and residual of a round are fetched ONE ROUND AHEAD (round 0: before the first exchange): issued next to their
     // use, each of the four residual loads of a round exposed a full HBM latency to all eight waves at once
     // (8x8 tile blocks: same round, before the exchange -- one buffer; the second costs that instantiation nine spills)
@@ -1272,7 +1278,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
     }
     if constexpr (AHEAD) prefetch(std::integral_constant<int, 0>{});
     [[maybe_unused]] float amx_o = 0.f, amx_a = 0.f;            // max |stored value| of this thread over the tile pass
-    static_for<4>([&](auto rc) {
+    static_for<2 * NC>([&](auto rc) {
       constexpr int rnd = decltype(rc)::value;
       constexpr int c = rnd >> 1, tg = rnd & 1, bf = AHEAD ? rnd & 1 : 0;
       if constexpr (!AHEAD) prefetch(rc);
@@ -1287,7 +1293,7 @@ __global__ __launch_bounds__(512) void conv_wino_bx3_wide_kernel(ConvArgs a, int
       IPDM_TE(1 + 4 * rnd);
       __syncthreads();
       IPDM_TE(2 + 4 * rnd);
-      if constexpr (AHEAD && rnd < 3) prefetch(std::integral_constant<int, rnd + 1>{});
+      if constexpr (AHEAD && rnd < 2 * NC - 1) prefetch(std::integral_constant<int, rnd + 1>{});
       constexpr int NSV = POOL ? 1 : 4;
       [[maybe_unused]] float sv[2][NSV];                      // STATS: this thread's stored values of the round
       if constexpr (STATS) {
@@ -1499,6 +1505,19 @@ bool x_small_dma(const ConvArgs& a) {
          (int64_t)a.B * (a.Cout / X_CO) >= min_pairs;
 }
 
+// 16-pixel layers with fewer than 512 output channels as 32-channel workgroups (CO32): what the f16x2 family's PLAIN call runs for
+// the shapes whose split-K rule says 2 (the host mirror then does not split: one launch instead of two K halves + a reduction;
+// IPDM_WBX3_CO32=0: off; a function of the layer shape only)
+bool x_co32(const ConvArgs& a) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("IPDM_WBX3_CO32");
+    enabled = e ? atoi(e) : 1;
+  }
+  return enabled && a.hx && a.dil == 1 && a.W <= 16 && a.H <= 16 && a.W % 4 == 0 && a.H % 2 == 0 && a.Cin >= 2 * X_KC &&
+         a.Cout < 512 && !a.pool2 && !a.stats;
+}
+
 int wino_persist() {                             // IPDM_WBX3_PERSIST=0: one workgroup per tile (tuning / fallback)
   static int persist = -1;
   if (persist < 0) {
@@ -1563,6 +1582,24 @@ static int conv_wino_bx3_launch_t(ConvArgs a, hipStream_t s) {
     return ipdm_launch_status();
   }
   const bool small = x_small(a);
+  if (HXV && small && wino_persist() && x_co32(a) && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0) {
+    a.tiles_x = (a.W + 15) / 16;
+    a.tiles_y = (a.H + 15) / 16;
+    a.co_tiles = a.Cout / 32;
+    const int64_t nblk = (int64_t)a.B * a.tiles_x * a.tiles_y * a.co_tiles;
+    if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
+    static bool co32_attr = false;
+    if (!co32_attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_bx3_wide_kernel<true, 8, 8, true, true, false, false, false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
+      co32_attr = true;
+    }
+    const int per_xcd = (int)((nblk + 7) / 8);
+    const int S = per_xcd < cus_per_xcd() ? per_xcd : cus_per_xcd();
+    hipLaunchKernelGGL((conv_wino_bx3_wide_kernel<true, 8, 8, true, true, false, false, false, false, true>), dim3((unsigned)(8 * S)),
+                       dim3(512), X_LDS_BYTES, s, a, (int)nblk);
+    return ipdm_launch_status();
+  }
   const bool small_dma = small && wino_persist() && x_small_dma(a);
   // the pooled epilogue lives in the persistent wide kernels only (the ConvMeanPool layers of the score nets are 32..128
   // pixels wide); everything else reports "unsupported" and the caller runs convolution + mean-pool separately

@@ -1362,7 +1362,7 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     nb = wino_bx3_max_batch(Cin, H, W, dilation)
-    ksplit = 1 if one_d or pool2 or x.data_ptr() % 16 else wino_bx3_splitk(Cin, Cout, H, W, dilation)
+    ksplit = 1 if one_d or pool2 or x.data_ptr() % 16 or (WBX3_CO32 and U.fmt == "hx2") else wino_bx3_splitk(Cin, Cout, H, W, dilation)
     if ksplit > 1:                       # 16-pixel layers with few channel tiles: two K halves + a fixed-order reduction
         for b0 in range(0, B, nb):
             b1 = min(B, b0 + nb)
@@ -1414,6 +1414,11 @@ def conv2d_wino_bx3(x, U, bias=None, residual=None, act_out=ACT_NONE, raw=True, 
     tag_amax(out, slot_o)
     tag_amax(out_act, slot_a)
     return (out, out_act) if want_act else out
+
+
+# f16x2 family: the 16-pixel layers whose split-K rule says "two K halves" run as ONE launch of 32-channel workgroups instead
+# (conv_wino_bx3.hip: CO32; -0.35 % per iteration and 28 reduction launches fewer; 0: the split-K form)
+WBX3_CO32 = os.environ.get("IPDM_WBX3_CO32", "1") != "0"
 
 
 def wino_bx3_pays(Cin, Cout, H, W, dilation=1, B=None):

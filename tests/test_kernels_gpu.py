@@ -676,10 +676,13 @@ def test_wino_bx3_statistics_epilogue(ops, B, Cin, Cout, H, W, pool, res, fmt):
 @pytest.mark.parametrize("B,Cin,Cout,H,W,res,act", [(3, 256, 256, 16, 16, True, True), (1, 64, 64, 16, 16, False, False),
                                                      (2, 512, 256, 16, 16, True, False), (2, 128, 128, 8, 16, False, True),
                                                      (5, 256, 128, 16, 12, True, True)])
-@pytest.mark.parametrize("fmt", ["bx3", "hx2"])
-def test_wino_bx3_split_k(ops, B, Cin, Cout, H, W, res, act, fmt):
+@pytest.mark.parametrize("fmt", ["bx3", "hx2", "hx2-co32"])
+def test_wino_bx3_split_k(ops, B, Cin, Cout, H, W, res, act, fmt, monkeypatch):
     """16-pixel layers with fewer than 512 output channels run as two K halves of the persistent Winograd kernel plus the
-    fixed-order reduction: against a float64 convolution, and bit-identical whatever the batch around a sample"""
+    fixed-order reduction -- or (f16x2 family, the default since round 4) as ONE launch of 32-channel workgroups: against a float64
+    convolution, and bit-identical whatever the batch around a sample"""
+    monkeypatch.setattr(ops, "WBX3_CO32", fmt == "hx2-co32")
+    fmt = fmt.split("-")[0]
     gen = torch.Generator().manual_seed(43)
     x = torch.randn(B, Cin, H, W, generator=gen)
     w = torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.05
