@@ -104,7 +104,10 @@ __global__ __launch_bounds__(256) void wino1d_weight_kernel(const float* __restr
 // VOL: 3x3x3 convolution of volumes [B][C][D][H][W] -- the depth taps are further K chunks (chunk = (kz, 16 channels): the raw rows of
 // plane z + kz - 1, hardware-zeroed outside the volume; 36 weight positions), and planes of 12 pixels or less go TWO per row block
 // (depth slices z, z+1 side by side: the producer zeroes the two neighbour values that cross the seam)
-template <int OUTS, bool STATS = false, bool POOL = false, bool FIN = false, bool VOL = false>
+// NBU = 3 (VOL, rows of exactly 12 used pixel pairs -- 24-pixel planes or two 12-pixel slices -- and 8-row blocks): the block's 8 x 12
+// used columns are numbered row * 12 + pair and fill THREE 32-column blocks completely, instead of 12 of 16 pairs in each of four:
+// a quarter of the MFMAs, operand reads and epilogue rounds gone
+template <int OUTS, bool STATS = false, bool POOL = false, bool FIN = false, bool VOL = false, int NBU = 4>
 __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_tiles) {
   extern __shared__ __align__(16) float lds[];
   unsigned* const ldsw = reinterpret_cast<unsigned*>(lds);
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
   const int HW = a.H * a.W;
   const int n_cc = a.Cin / Y_KC, n_ct = a.Cout / 32;
   static_assert(!VOL || (!STATS && !POOL && !FIN), "VOL: plain epilogues");
+  static_assert(NBU == 4 || (NBU == 3 && VOL), "compact columns: the volume form");
   const int n_chunks = VOL ? 3 * n_cc : n_cc;                  // even, >= 2 (launcher)
   const int CS = VOL ? a.D * HW : HW;                          // channel stride of input / output
   const bool pack = VOL && a.W <= 12;                          // two depth slices per row block
@@ -329,17 +333,26 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
       for (int s = 0; s < 2; ++s) fr[c][s] = base[c * 128 + s * 64];
   };
   const int b_lane = (j >> 4) * Y_RS + xi * 256 + h * 32 + (j & 15);
-  auto load_B = [&](uint4 (&fr)[2], const unsigned* cur, int r) {
-    const unsigned* bp = cur + r * Y_RS + b_lane;
+  [[maybe_unused]] int b_cmp[3] = {0, 0, 0};                    // NBU == 3: this lane's (row, pair) of column 32 nb + j, as a word offset
+  if constexpr (NBU == 3) {
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) {
+      const int n = 32 * nb + j;
+      b_cmp[nb] = (n / 12) * Y_RS + xi * 256 + h * 32 + n % 12;
+    }
+  }
+  auto load_B = [&](uint4 (&fr)[2], const unsigned* cur, auto kyc, auto nbc) {
+    constexpr int ky = decltype(kyc)::value, nb = decltype(nbc)::value;
+    const unsigned* bp = NBU == 3 ? cur + ky * Y_RS + b_cmp[nb < 3 ? nb : 0] : cur + (2 * nb + ky) * Y_RS + b_lane;
 #pragma unroll
     for (int s = 0; s < 2; ++s) fr[s] = make_uint4(bp[s * 128], bp[s * 128 + 16], bp[s * 128 + 64], bp[s * 128 + 80]);
   };
 
-  f32x16 acc[2][4];
+  f32x16 acc[2][NBU];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 2 * NBU; ++i)
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) acc[i >> 2][i & 3][rr] = 0.f;
+    for (int rr = 0; rr < 16; ++rr) acc[i / NBU][i % NBU][rr] = 0.f;
 
   auto lds_barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
@@ -410,19 +423,20 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
         // the wave's DMA of chunk ch+1 (issued a chunk ago) has landed: three fragment groups are younger, two of them still wanted
         __builtin_amdgcn_s_waitcnt(0x0F78);                     // vmcnt(8)
         read_items();
-        load_B(bsh[0], cur, 0);
+        load_B(bsh[0], cur, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the raw rows are in registers
         issue_dma(dma_chunk);
         __builtin_amdgcn_sched_barrier(0);
         float va[4], vb[4];
-        static_for<12>([&](auto ssc) {
+        static_for<3 * NBU>([&](auto ssc) {
           constexpr int ss = decltype(ssc)::value;
-          constexpr int ky = ss >> 2, nb = ss & 3;
+          constexpr int ky = ss / NBU, nb = ss % NBU;
           constexpr int aslot = (cpar * 3 + ky) & 1;
-          if constexpr (ss < 11) load_B(bsh[(ss + 1) & 1], cur, 2 * ((ss + 1) & 3) + ((ss + 1) >> 2));
-          // producer work of item ss / 4, dealt over the four sub-steps of a filter row
-          constexpr int it = ss >> 2;
+          if constexpr (ss < 3 * NBU - 1)
+            load_B(bsh[(ss + 1) & 1], cur, std::integral_constant<int, (ss + 1) / NBU>{}, std::integral_constant<int, (ss + 1) % NBU>{});
+          // producer work of item ky, dealt over the sub-steps of a filter row
+          constexpr int it = ky;
           if constexpr (nb == 0) xform_item(std::integral_constant<int, it>{}, va, vb);
           if constexpr (nb == 1) store_item(nxt, std::integral_constant<int, it>{}, va, vb, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
           if constexpr (nb == 2) store_item(nxt, std::integral_constant<int, it>{}, va, vb, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
@@ -435,13 +449,13 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
             v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr[aslot][c][0]), bh, v, 0, 0, 0);
             acc[c][nb] = v;
           }
-          if constexpr (nb == 3) {
+          if constexpr (nb == NBU - 1) {
             // this filter row's fragments are free: request the row after next (same slot)
             if constexpr (ky == 0) load_A(afr[aslot], 2, ch, cur_g.cob);
             if constexpr (ky == 1) load_A(afr[aslot], 0, a_chunk, a_cob);
             if constexpr (ky == 2) load_A(afr[aslot], 1, a_chunk, a_cob);
           }
-          if constexpr (ss < 11) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // next sub-step's operand reads first
+          if constexpr (ss < 3 * NBU - 1) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // next sub-step's operand reads first
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -473,10 +487,18 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
     const int e_pair = e_isb ? (ecol & 15) - seam : (ecol & 15);
     unsigned eoff4 = 4u * (unsigned)(ecg * oHW + (POOL ? (ecol & 15) : (ecol >> 4) * oW + 2 * e_pair + (e_isb ? HW : 0)));
     asm volatile("" : "+v"(eoff4));
+    // NBU == 3: column 32 nb + ecol is (row, pair) = divmod(., 12); pairs 6 .. 11 of a two-slice block are the second slice's 0 .. 5
+    [[maybe_unused]] auto cmp_off = [&](int nb) -> unsigned {
+      const int n = 32 * nb + ecol, row = n / 12, pr = n % 12;
+      const bool isb = pack && pr >= 6;
+      return 4u * (unsigned)(ecg * oHW + row * oW + 2 * (isb ? pr - 6 : pr) + (isb ? HW : 0));
+    };
     auto boff = [&](int c, int nb, int k) -> unsigned {
+      if constexpr (NBU == 3) return 4u * (unsigned)((((k >> 1) * 2 + c) * 32 + (k & 1) * 16) * oHW) + cmp_off(nb);
       return 4u * (unsigned)((((k >> 1) * 2 + c) * 32 + (k & 1) * 16) * oHW + (POOL ? nb : 2 * nb) * oW) + eoff4;
     };
     auto in_range = [&](int nb) {
+      if constexpr (NBU == 3) return !(pack && (32 * nb + ecol) % 12 >= 6) || cur_g.z + 1 < a.D;     // (8 full rows, 12 used pairs)
       const bool row_ok = cur_g.y0 + 2 * nb + (ecol >> 4) < a.H;
       if constexpr (VOL) {
         if (pack) return row_ok && (ecol & 15) < 2 * seam && (!e_isb || cur_g.z + 1 < a.D);
@@ -496,7 +518,7 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
     // (unconditional loads -- an absent operand or an out-of-range column reads the weight blob -- so that hipcc can count them)
     auto prefetch = [&](auto rc) {
       constexpr int rnd = decltype(rc)::value;
-      constexpr int c = rnd >> 2, nb = rnd & 3, bf = rnd & 1;
+      constexpr int c = rnd / NBU, nb = rnd % NBU, bf = rnd & 1;
       const bool res_ok = has_res && in_range(nb) && (!POOL || (ecol >> 4) == 0);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -526,9 +548,9 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
 #else
 #define W1D_TE(k)
 #endif
-    static_for<8>([&](auto rc) {
+    static_for<2 * NBU>([&](auto rc) {
       constexpr int rnd = decltype(rc)::value;
-      constexpr int c = rnd >> 2, nb = rnd & 3, bf = rnd & 1;
+      constexpr int c = rnd / NBU, nb = rnd % NBU, bf = rnd & 1;
       float* const mw = ms + (rnd & 1) * Y_M;
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) {
@@ -539,7 +561,7 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
       W1D_TE(0);
       __syncthreads();
       W1D_TE(1);
-      if constexpr (rnd < 7) prefetch(std::integral_constant<int, rnd + 1>{});
+      if constexpr (rnd < 2 * NBU - 1) prefetch(std::integral_constant<int, rnd + 1>{});
       const bool inr = in_range(nb) && (!POOL || (ecol >> 4) == 0);   // this thread stores (POOL: the windows' upper rows do)
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -623,7 +645,7 @@ __global__ __launch_bounds__(512) void conv_wino1d_kernel(ConvArgs a, int total_
         if constexpr (nb == 0) st_c0 = st_c1 = 0;
         st_c0 += NV * __popcll(bal & 0xffffffffull);
         st_c1 += NV * __popcll(bal >> 32);
-        if constexpr (nb == 3) {
+        if constexpr (nb == NBU - 1) {
           const float cnt = (float)(h ? st_c1 : st_c0);
           const int tb = (cur_g.y0 / Y_ROWS) * a.tiles_x + cur_g.x0 / (2 * Y_TX);
           const int n_tb = a.tiles_x * a.tiles_y;
@@ -827,11 +849,20 @@ int conv_wino1d_vol_launch(ConvArgs a, hipStream_t s) {
   a.co_tiles = a.Cout / Y_CO;
   const int64_t nblk = (int64_t)a.B * (pack ? (a.D + 1) / 2 : a.D) * a.tiles_x * a.tiles_y * a.co_tiles;
   if (nblk > 0x7fffffff) return IPDM_EUNSUPPORTED;
+  static int compact = -1;                       // IPDM_W1D_COMPACT=0: four column blocks everywhere (tuning / fallback)
+  if (compact < 0) {
+    const char* e = getenv("IPDM_W1D_COMPACT");
+    compact = e ? atoi(e) : 1;
+  }
+  const bool nbu3 = compact && a.H % Y_ROWS == 0 && (pack ? a.W == 12 : a.W == 24);     // exactly 12 used pairs in each of 8 rows
   static bool attr_set = false;
   if (!attr_set) {
     const void* kernels[] = {reinterpret_cast<const void*>(conv_wino1d_kernel<1, false, false, false, true>),
                              reinterpret_cast<const void*>(conv_wino1d_kernel<2, false, false, false, true>),
-                             reinterpret_cast<const void*>(conv_wino1d_kernel<3, false, false, false, true>)};
+                             reinterpret_cast<const void*>(conv_wino1d_kernel<3, false, false, false, true>),
+                             reinterpret_cast<const void*>(conv_wino1d_kernel<1, false, false, false, true, 3>),
+                             reinterpret_cast<const void*>(conv_wino1d_kernel<2, false, false, false, true, 3>),
+                             reinterpret_cast<const void*>(conv_wino1d_kernel<3, false, false, false, true, 3>)};
     for (const void* k : kernels) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Y_LDS_BYTES);
       if (e != hipSuccess) return (int)e;
@@ -844,6 +875,15 @@ int conv_wino1d_vol_launch(ConvArgs a, hipStream_t s) {
   const int per_xcd = (int)((nblk + 7) / 8);
   const int S = per_xcd < cus / 8 ? per_xcd : cus / 8;
   const int outs = (a.out ? 1 : 0) | (a.out_act ? 2 : 0);
+  if (nbu3) {
+    if (outs == 3)
+      hipLaunchKernelGGL((conv_wino1d_kernel<3, false, false, false, true, 3>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
+    else if (outs == 1)
+      hipLaunchKernelGGL((conv_wino1d_kernel<1, false, false, false, true, 3>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
+    else
+      hipLaunchKernelGGL((conv_wino1d_kernel<2, false, false, false, true, 3>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
+    return ipdm_launch_status();
+  }
   if (outs == 3)
     hipLaunchKernelGGL((conv_wino1d_kernel<3, false, false, false, true>), dim3((unsigned)(8 * S)), dim3(512), Y_LDS_BYTES, s, a, (int)nblk);
   else if (outs == 1)
